@@ -1,0 +1,187 @@
+/*
+ * amdretrieval.h — C ABI of libamdretrieval.so (MI355X / gfx950 hybrid-retrieval kernels).
+ *
+ * The reference (Fan-Luo/Legal-RAG) is 100 % Python and has no FFI of its own
+ * (SURVEY.md §8b); its native arithmetic lives in third-party wheels.  Each entry
+ * point below therefore cites the reference CALL SITE whose native callee it
+ * replaces.  Conventions: plain pointers and sizes only; every function returns
+ * 0 on success or a negative AMDR_E* code, with a thread-local message available
+ * from amdr_last_error(); the caller allocates all outputs; opaque handles are
+ * safe for concurrent read-only searches (internally serialised per handle),
+ * mutation (add/destroy) must not race with searches on the same handle.
+ *
+ * "_device" variants take DEVICE pointers and a hipStream_t passed as void*
+ * (0 = the null stream); they enqueue work and return without synchronising,
+ * and are graph-capturable once amdr_*_reserve() has sized the workspace.
+ * Plain variants take HOST pointers, run on the handle's private stream and
+ * return after the results are in the host buffers.
+ */
+#ifndef AMDRETRIEVAL_H
+#define AMDRETRIEVAL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMDR_OK 0
+#define AMDR_EINVAL (-1)   /* bad argument (null, shape, k out of range) */
+#define AMDR_EHIP (-2)     /* a HIP runtime call failed; see amdr_last_error() */
+#define AMDR_ENOMEM (-3)   /* device or host allocation failed */
+#define AMDR_ENODEV (-4)   /* no usable gfx950 device */
+
+#define AMDR_MAX_K 256      /* per-channel depth limit of the fused top-k kernels */
+#define AMDR_MAX_DIM 1024   /* dense embedding dim limit (multiple of 4) */
+#define AMDR_MAXSIM_DIM 128 /* ColBERT token dim (fixed by the kernel's register layout) */
+#define AMDR_MAXSIM_QLEN 32 /* ColBERT query length after [MASK] padding */
+
+typedef struct amdr_dense amdr_dense_t;
+typedef struct amdr_bm25 amdr_bm25_t;
+typedef struct amdr_maxsim amdr_maxsim_t;
+
+/* ---- library ---------------------------------------------------------- */
+const char* amdr_last_error(void);
+int amdr_version(void);                     /* 10000*major + 100*minor + patch */
+int amdr_device_count(int32_t* count);      /* number of visible HIP devices   */
+int amdr_device_name(int32_t device, char* buf, int32_t buf_len); /* gcnArchName */
+
+/* ---- dense channel: exact inner-product top-k -------------------------
+ * Replaces faiss `index.add(emb)` (legalrag/retrieval/builders/faiss_builder.py:91,
+ * incremental_dense_builder.py:62) and `index.search(q_vec, k)`
+ * (legalrag/retrieval/dense_retriever.py:42, vector_store.py:169).
+ * X: row-major fp32 [n, d] (rows L2-normalised by the encoder).  Results are
+ * sorted by score descending, ties -> lower row id, padded with id -1 and
+ * score -FLT_MAX when k > n (faiss convention). */
+int amdr_dense_create(const float* X_host, int64_t n, int32_t d, int32_t device, amdr_dense_t** out);
+/* adopt an existing device matrix without copying (the caller keeps ownership
+ * and must keep it alive); used for shards generated in HBM */
+int amdr_dense_create_from_device(const float* X_dev, int64_t n, int32_t d, int32_t device, amdr_dense_t** out);
+int amdr_dense_add(amdr_dense_t* h, const float* X_host, int64_t n_add);
+int amdr_dense_ntotal(const amdr_dense_t* h, int64_t* n);
+int amdr_dense_dim(const amdr_dense_t* h, int32_t* d);
+int amdr_dense_reserve(amdr_dense_t* h, int32_t nq_max, int32_t k_max);
+int amdr_dense_search(amdr_dense_t* h, const float* Q_host, int32_t nq, int32_t k,
+                      float* scores_host, int64_t* ids_host);
+int amdr_dense_search_device(amdr_dense_t* h, const float* Q_dev, int32_t nq, int32_t k,
+                             float* scores_dev, int64_t* ids_dev, void* stream);
+/* copy rows [row0, row0+nrows) back to the host (used by parity tests to run
+ * the oracle on exactly the matrix that is resident in HBM) */
+int amdr_dense_read_rows(const amdr_dense_t* h, int64_t row0, int64_t nrows, float* out_host);
+int amdr_dense_destroy(amdr_dense_t* h);
+
+/* ---- BM25 channel: Okapi scoring over term-major CSR postings ----------
+ * Replaces `BM25Okapi.get_scores(tokens)` + the full Python sort
+ * (legalrag/retrieval/bm25_retriever.py:74-75).  float64 throughout, no FMA
+ * contraction; per document the query tokens are accumulated in query order
+ * with duplicates counted, so scores are bit-identical to rank_bm25's numpy
+ * expression.  Ties -> lower doc id; zero-score docs ARE returned.
+ * term_ptr[n_terms+1] indexes post_doc/post_tf (ascending doc id per term);
+ * idf already has rank_bm25's epsilon floor applied. */
+int amdr_bm25_create(const int64_t* term_ptr, const int32_t* post_doc, const int32_t* post_tf,
+                     const double* idf, const int32_t* doc_len, int64_t n_terms, int64_t n_docs,
+                     double avgdl, double k1, double b, int32_t device, amdr_bm25_t** out);
+int amdr_bm25_ndocs(const amdr_bm25_t* h, int64_t* n);
+int amdr_bm25_reserve(amdr_bm25_t* h, int32_t nq_max, int32_t k_max, int64_t total_terms_max);
+/* queries as CSR: q_terms[q_ptr[i] .. q_ptr[i+1]) = term ids of query i in
+ * token order (unknown tokens: any negative id, they score 0) */
+int amdr_bm25_search(amdr_bm25_t* h, const int32_t* q_terms, const int64_t* q_ptr, int32_t nq, int32_t k,
+                     double* scores_host, int64_t* ids_host);
+int amdr_bm25_search_device(amdr_bm25_t* h, const int32_t* q_terms_dev, const int64_t* q_ptr_dev,
+                            int32_t nq, int32_t k, double* scores_dev, int64_t* ids_dev, void* stream);
+/* dense score vectors [nq, n_docs] == BM25Okapi.get_scores per query */
+int amdr_bm25_scores(amdr_bm25_t* h, const int32_t* q_terms, const int64_t* q_ptr, int32_t nq,
+                     double* scores_host);
+int amdr_bm25_destroy(amdr_bm25_t* h);
+
+/* ---- ColBERT channel: exhaustive late-interaction MaxSim ---------------
+ * Replaces `Searcher.search(query, k)` (legalrag/retrieval/colbert_retriever.py:152).
+ * D: fp32 token embeddings [total_tokens, 128], doc_ptr[n_docs+1] (every doc
+ * has >= 1 token); Q: [nq, 32, 128].  score = sum_i max_j <q_i, d_j>. */
+int amdr_maxsim_create(const float* D_host, const int64_t* doc_ptr, int64_t n_docs, int32_t dim,
+                       int32_t device, amdr_maxsim_t** out);
+int amdr_maxsim_ndocs(const amdr_maxsim_t* h, int64_t* n);
+int amdr_maxsim_reserve(amdr_maxsim_t* h, int32_t nq_max, int32_t k_max);
+int amdr_maxsim_search(amdr_maxsim_t* h, const float* Q_host, int32_t nq, int32_t q_len, int32_t k,
+                       float* scores_host, int64_t* ids_host);
+int amdr_maxsim_search_device(amdr_maxsim_t* h, const float* Q_dev, int32_t nq, int32_t q_len, int32_t k,
+                              float* scores_dev, int64_t* ids_dev, void* stream);
+int amdr_maxsim_scores(amdr_maxsim_t* h, const float* Q_host, int32_t nq, int32_t q_len, float* scores_host);
+int amdr_maxsim_destroy(amdr_maxsim_t* h);
+
+/* ---- fusion + rerank blend ---------------------------------------------
+ * Replaces HybridRetriever._fuse (legalrag/retrieval/hybrid_retriever.py:389-551)
+ * with its helpers _minmax (:24-30) and _rrf_with_breakdown (:33-56), the
+ * min_final_score filter (:309-310) and the rerank blend (:338-355 with
+ * rerankers.py:48-54,349).  float64, no FMA contraction: bit-identical to the
+ * Python float arithmetic.  Exactly tied fused scores keep first-appearance
+ * order (dense list, then bm25, then colbert). */
+#define AMDR_FUSE_RRF_NORM_BLEND 0
+#define AMDR_FUSE_RRF 1
+#define AMDR_FUSE_WRRF 2
+#define AMDR_FUSE_WEIGHTED_SUM 3
+
+typedef struct amdr_fuse_params {
+  int32_t method;          /* AMDR_FUSE_* */
+  int32_t rrf_k;           /* cfg.retrieval.rrf_k (60) */
+  double alpha;            /* cfg.retrieval.rrf_alpha (0.5) */
+  double w_dense, w_bm25, w_colbert;
+  double min_final_score;  /* drop fused hits below this; -inf keeps all */
+} amdr_fuse_params_t;
+
+/* values per fused candidate, AMDR_FUSE_NVALS doubles each */
+#define AMDR_FUSE_NVALS 9
+#define AMDR_FV_SCORE 0
+#define AMDR_FV_RRF_NORM 1
+#define AMDR_FV_WSUM 2
+#define AMDR_FV_NORM_DENSE 3
+#define AMDR_FV_NORM_BM25 4
+#define AMDR_FV_NORM_COLBERT 5
+#define AMDR_FV_CONTRIB_DENSE 6
+#define AMDR_FV_CONTRIB_BM25 7
+#define AMDR_FV_CONTRIB_COLBERT 8
+
+/* Inputs per channel: ids [nq, k_c] (-1 = padding, valid entries first, sorted
+ * by score descending), scores [nq, k_c]; a channel with k_c == 0 is absent.
+ * *_row2uid (nullable) maps a channel's row id to the corpus-wide chunk uid.
+ * Outputs, max_out = kd+kb+kc entries per query, in fused-rank order:
+ * out_ids [nq,max_out], out_vals [nq,max_out,AMDR_FUSE_NVALS], out_mask
+ * [nq,max_out] (bit0 dense, bit1 bm25, bit2 colbert membership), out_count
+ * [nq] = hits surviving the min_final_score filter. */
+int amdr_fuse(const amdr_fuse_params_t* p, int32_t nq,
+              const int64_t* dense_ids, const float* dense_scores, int32_t kd,
+              const int64_t* bm25_ids, const double* bm25_scores, int32_t kb,
+              const int64_t* colbert_ids, const float* colbert_scores, int32_t kc,
+              int64_t* out_ids, double* out_vals, int32_t* out_mask, int32_t* out_count);
+int amdr_fuse_device(const amdr_fuse_params_t* p, int32_t nq,
+                     const int64_t* dense_ids, const float* dense_scores, int32_t kd, const int64_t* dense_row2uid,
+                     const int64_t* bm25_ids, const double* bm25_scores, int32_t kb, const int64_t* bm25_row2uid,
+                     const int64_t* colbert_ids, const float* colbert_scores, int32_t kc, const int64_t* colbert_row2uid,
+                     int64_t* out_ids, double* out_vals, int32_t* out_mask, int32_t* out_count,
+                     int32_t device, void* stream);
+
+/* Rerank blend over the first min(top_n, count[q]) fused hits of each query:
+ * norm = minmax(ce_raw); score = (1-beta)*score + beta*norm; the candidates
+ * are re-ordered by norm (stable), written back in front of the rest, and the
+ * whole list is stably re-sorted by the new score.  In place on ids/vals/mask;
+ * out_rerank [nq,max_out,2] receives (raw, norm) per OUTPUT position, NaN for
+ * hits that were not reranked. ce_raw: [nq, top_n]. */
+int amdr_rerank_blend(int32_t nq, int32_t max_out, const int32_t* count, int64_t* ids, double* vals,
+                      int32_t* mask, const double* ce_raw, int32_t top_n, double beta, double* out_rerank);
+int amdr_rerank_blend_device(int32_t nq, int32_t max_out, const int32_t* count, int64_t* ids, double* vals,
+                             int32_t* mask, const double* ce_raw, int32_t top_n, double beta,
+                             double* out_rerank, int32_t device, void* stream);
+
+/* ---- multi-GPU: merge per-shard top-k after the RCCL all-gather --------
+ * No reference counterpart (the reference is single-process).
+ * parts: [n_parts, nq, k_in] scores + GLOBAL ids (-1 padding); output
+ * [nq, k_out], score descending, ties -> lower global id. */
+int amdr_merge_topk_f32_device(const float* scores, const int64_t* ids, int32_t n_parts, int32_t nq, int32_t k_in,
+                               int32_t k_out, float* out_scores, int64_t* out_ids, int32_t device, void* stream);
+int amdr_merge_topk_f64_device(const double* scores, const int64_t* ids, int32_t n_parts, int32_t nq, int32_t k_in,
+                               int32_t k_out, double* out_scores, int64_t* out_ids, int32_t device, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMDRETRIEVAL_H */

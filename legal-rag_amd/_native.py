@@ -1,0 +1,407 @@
+"""ctypes binding of libamdretrieval.so (include/amdretrieval.h).
+
+There is NO CPU fallback: if the shared library is missing or a call fails the
+error is raised to the caller.  The GIL is released for the duration of every
+native call (ctypes.CDLL), so concurrent searches from the retrieval service's
+thread pool overlap their host-side work.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from pathlib import Path
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+LIB_NAME = "libamdretrieval.so"
+MAX_K = 256
+MAX_DIM = 1024
+MAXSIM_DIM = 128
+MAXSIM_QLEN = 32
+FUSE_NVALS = 9
+FUSE_METHODS = {"rrf_norm_blend": 0, "rrf": 1, "wrrf": 2, "weighted_sum": 3}
+FV = dict(score=0, rrf_norm=1, weighted_sum=2, dense_norm=3, bm25_norm=4, colbert_norm=5,
+          contrib_dense=6, contrib_bm25=7, contrib_colbert=8)
+
+# every symbol include/amdretrieval.h declares (checked by tests/test_abi.py)
+EXPORTS = (
+    "amdr_last_error", "amdr_version", "amdr_device_count", "amdr_device_name",
+    "amdr_dense_create", "amdr_dense_create_from_device", "amdr_dense_add", "amdr_dense_ntotal", "amdr_dense_dim",
+    "amdr_dense_reserve", "amdr_dense_search", "amdr_dense_search_device", "amdr_dense_read_rows",
+    "amdr_dense_destroy",
+    "amdr_bm25_create", "amdr_bm25_ndocs", "amdr_bm25_reserve", "amdr_bm25_search", "amdr_bm25_search_device",
+    "amdr_bm25_scores", "amdr_bm25_destroy",
+    "amdr_maxsim_create", "amdr_maxsim_ndocs", "amdr_maxsim_reserve", "amdr_maxsim_search",
+    "amdr_maxsim_search_device", "amdr_maxsim_scores", "amdr_maxsim_destroy",
+    "amdr_fuse", "amdr_fuse_device", "amdr_rerank_blend", "amdr_rerank_blend_device",
+    "amdr_merge_topk_f32_device", "amdr_merge_topk_f64_device",
+)
+
+
+class NativeError(RuntimeError):
+    """A libamdretrieval call returned a non-zero status."""
+
+
+class FuseParams(C.Structure):
+    _fields_ = [("method", C.c_int32), ("rrf_k", C.c_int32), ("alpha", C.c_double), ("w_dense", C.c_double),
+                ("w_bm25", C.c_double), ("w_colbert", C.c_double), ("min_final_score", C.c_double)]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib_path() -> Path:
+    env = os.environ.get("AMDR_LIB")
+    if env:
+        return Path(env)
+    return Path(__file__).resolve().parent / "lib" / LIB_NAME
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not p.exists():
+        raise NativeError(
+            f"{p} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(or `make -C legal-rag_amd/csrc`). There is no CPU fallback.")
+    lib = C.CDLL(str(p))
+    lib.amdr_last_error.restype = C.c_char_p
+    for name in EXPORTS:
+        fn = getattr(lib, name)  # raises AttributeError if a declared symbol is missing
+        if name != "amdr_last_error":
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().amdr_last_error()
+        raise NativeError(f"{what} failed (status {rc}): {msg.decode('utf-8', 'replace') if msg else ''}")
+
+
+def device_count() -> int:
+    n = C.c_int32(0)
+    rc = load().amdr_device_count(C.byref(n))
+    return int(n.value) if rc == 0 else 0
+
+
+def device_name(device: int = 0) -> str:
+    buf = C.create_string_buffer(256)
+    _check(load().amdr_device_name(C.c_int32(device), buf, C.c_int32(256)), "amdr_device_name")
+    return buf.value.decode()
+
+
+def _p(a: Optional[np.ndarray], ctype):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+def _vp(ptr: int):
+    return C.c_void_p(int(ptr) if ptr else 0)
+
+
+def _c(a, dtype) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+# ---------------------------------------------------------------------------
+class DenseIndex:
+    """Exact inner-product index resident in HBM (replaces faiss IndexFlatIP /
+    IndexHNSWFlat behind `index.search`, dense_retriever.py:42)."""
+
+    def __init__(self, X: Optional[np.ndarray] = None, *, device: int = 0, dim: Optional[int] = None,
+                 device_ptr: Optional[int] = None, n: Optional[int] = None, keepalive=None):
+        lib = load()
+        self._h = C.c_void_p()
+        self.device = int(device)
+        self._keepalive = keepalive
+        if device_ptr is not None:
+            assert n is not None and dim is not None
+            _check(lib.amdr_dense_create_from_device(_vp(device_ptr), C.c_int64(n), C.c_int32(dim),
+                                                     C.c_int32(device), C.byref(self._h)),
+                   "amdr_dense_create_from_device")
+            self.d = int(dim)
+        else:
+            if X is None:
+                X = np.zeros((0, int(dim)), dtype=np.float32)
+            X = _c(X, np.float32)
+            if X.ndim != 2:
+                raise ValueError("X must be [n, d]")
+            self.d = int(X.shape[1])
+            _check(lib.amdr_dense_create(_p(X, C.c_float), C.c_int64(X.shape[0]), C.c_int32(self.d),
+                                         C.c_int32(device), C.byref(self._h)), "amdr_dense_create")
+
+    @property
+    def ntotal(self) -> int:
+        n = C.c_int64(0)
+        _check(load().amdr_dense_ntotal(self._h, C.byref(n)), "amdr_dense_ntotal")
+        return int(n.value)
+
+    def add(self, X: np.ndarray) -> None:
+        X = _c(X, np.float32)
+        if X.ndim != 2 or X.shape[1] != self.d:
+            raise ValueError(f"add: expected [*, {self.d}]")
+        _check(load().amdr_dense_add(self._h, _p(X, C.c_float), C.c_int64(X.shape[0])), "amdr_dense_add")
+
+    def reserve(self, nq_max: int, k_max: int) -> None:
+        _check(load().amdr_dense_reserve(self._h, C.c_int32(nq_max), C.c_int32(k_max)), "amdr_dense_reserve")
+
+    def search(self, Q: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray]:
+        """faiss-shaped: (scores f32[nq,k], ids i64[nq,k]), -1 padded."""
+        Q = _c(Q, np.float32)
+        if Q.ndim == 1:
+            Q = Q[None, :]
+        if Q.shape[1] != self.d:
+            raise ValueError(f"search: query dim {Q.shape[1]} != index dim {self.d}")
+        nq = Q.shape[0]
+        scores = np.empty((nq, k), dtype=np.float32)
+        ids = np.empty((nq, k), dtype=np.int64)
+        _check(load().amdr_dense_search(self._h, _p(Q, C.c_float), C.c_int32(nq), C.c_int32(k),
+                                        _p(scores, C.c_float), _p(ids, C.c_int64)), "amdr_dense_search")
+        return scores, ids
+
+    def search_device(self, q_ptr: int, nq: int, k: int, scores_ptr: int, ids_ptr: int, stream: int = 0) -> None:
+        _check(load().amdr_dense_search_device(self._h, _vp(q_ptr), C.c_int32(nq), C.c_int32(k), _vp(scores_ptr),
+                                               _vp(ids_ptr), _vp(stream)), "amdr_dense_search_device")
+
+    def read_rows(self, row0: int, nrows: int) -> np.ndarray:
+        out = np.empty((nrows, self.d), dtype=np.float32)
+        _check(load().amdr_dense_read_rows(self._h, C.c_int64(row0), C.c_int64(nrows), _p(out, C.c_float)),
+               "amdr_dense_read_rows")
+        return out
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) and self._h.value:
+            load().amdr_dense_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------
+class BM25Index:
+    """Okapi BM25 over term-major CSR postings (replaces BM25Okapi.get_scores +
+    the Python sort, bm25_retriever.py:74-75)."""
+
+    def __init__(self, term_ptr, post_doc, post_tf, idf, doc_len, avgdl: float, k1: float = 1.5, b: float = 0.75,
+                 *, device: int = 0):
+        lib = load()
+        self._arrs = (_c(term_ptr, np.int64), _c(post_doc, np.int32), _c(post_tf, np.int32), _c(idf, np.float64),
+                      _c(doc_len, np.int32))
+        tp, pd, pt, idf_, dl = self._arrs
+        self.n_terms = int(tp.shape[0] - 1)
+        self.n_docs = int(dl.shape[0])
+        self.device = int(device)
+        self._h = C.c_void_p()
+        _check(lib.amdr_bm25_create(_p(tp, C.c_int64), _p(pd, C.c_int32), _p(pt, C.c_int32), _p(idf_, C.c_double),
+                                    _p(dl, C.c_int32), C.c_int64(self.n_terms), C.c_int64(self.n_docs),
+                                    C.c_double(avgdl), C.c_double(k1), C.c_double(b), C.c_int32(device),
+                                    C.byref(self._h)), "amdr_bm25_create")
+        self._arrs = None  # the library holds its own device copy
+
+    @staticmethod
+    def pack_queries(queries: Sequence[Sequence[int]]) -> Tuple[np.ndarray, np.ndarray]:
+        q_ptr = np.zeros(len(queries) + 1, dtype=np.int64)
+        for i, q in enumerate(queries):
+            q_ptr[i + 1] = q_ptr[i] + len(q)
+        q_terms = np.empty(max(int(q_ptr[-1]), 1), dtype=np.int32)
+        for i, q in enumerate(queries):
+            q_terms[q_ptr[i]:q_ptr[i + 1]] = np.asarray(q, dtype=np.int32).reshape(-1)
+        return q_terms, q_ptr
+
+    def reserve(self, nq_max: int, k_max: int, total_terms_max: int) -> None:
+        _check(load().amdr_bm25_reserve(self._h, C.c_int32(nq_max), C.c_int32(k_max), C.c_int64(total_terms_max)),
+               "amdr_bm25_reserve")
+
+    def search(self, queries: Sequence[Sequence[int]], k: int) -> Tuple[np.ndarray, np.ndarray]:
+        q_terms, q_ptr = self.pack_queries(queries)
+        nq = len(queries)
+        scores = np.empty((nq, k), dtype=np.float64)
+        ids = np.empty((nq, k), dtype=np.int64)
+        _check(load().amdr_bm25_search(self._h, _p(q_terms, C.c_int32), _p(q_ptr, C.c_int64), C.c_int32(nq),
+                                       C.c_int32(k), _p(scores, C.c_double), _p(ids, C.c_int64)), "amdr_bm25_search")
+        return scores, ids
+
+    def search_device(self, q_terms_ptr: int, q_ptr_ptr: int, nq: int, k: int, scores_ptr: int, ids_ptr: int,
+                      stream: int = 0) -> None:
+        _check(load().amdr_bm25_search_device(self._h, _vp(q_terms_ptr), _vp(q_ptr_ptr), C.c_int32(nq), C.c_int32(k),
+                                              _vp(scores_ptr), _vp(ids_ptr), _vp(stream)), "amdr_bm25_search_device")
+
+    def get_scores(self, queries: Sequence[Sequence[int]]) -> np.ndarray:
+        q_terms, q_ptr = self.pack_queries(queries)
+        nq = len(queries)
+        out = np.empty((nq, self.n_docs), dtype=np.float64)
+        _check(load().amdr_bm25_scores(self._h, _p(q_terms, C.c_int32), _p(q_ptr, C.c_int64), C.c_int32(nq),
+                                       _p(out, C.c_double)), "amdr_bm25_scores")
+        return out
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) and self._h.value:
+            load().amdr_bm25_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------
+class MaxSimIndex:
+    """Exhaustive ColBERT late interaction over fp32 token embeddings."""
+
+    def __init__(self, D: np.ndarray, doc_ptr: np.ndarray, *, device: int = 0):
+        D = _c(D, np.float32)
+        doc_ptr = _c(doc_ptr, np.int64)
+        if D.ndim != 2:
+            raise ValueError("D must be [tokens, dim]")
+        self.dim = int(D.shape[1])
+        self.n_docs = int(doc_ptr.shape[0] - 1)
+        self.device = int(device)
+        if int(doc_ptr[-1]) != D.shape[0]:
+            raise ValueError("doc_ptr[-1] != number of token rows")
+        self._h = C.c_void_p()
+        _check(load().amdr_maxsim_create(_p(D, C.c_float), _p(doc_ptr, C.c_int64), C.c_int64(self.n_docs),
+                                         C.c_int32(self.dim), C.c_int32(device), C.byref(self._h)),
+               "amdr_maxsim_create")
+
+    def reserve(self, nq_max: int, k_max: int) -> None:
+        _check(load().amdr_maxsim_reserve(self._h, C.c_int32(nq_max), C.c_int32(k_max)), "amdr_maxsim_reserve")
+
+    def _q(self, Q):
+        Q = _c(Q, np.float32)
+        if Q.ndim == 2:
+            Q = Q[None]
+        if Q.ndim != 3 or Q.shape[2] != self.dim:
+            raise ValueError(f"Q must be [nq, q_len, {self.dim}]")
+        return Q
+
+    def search(self, Q: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray]:
+        Q = self._q(Q)
+        nq, q_len = Q.shape[0], Q.shape[1]
+        scores = np.empty((nq, k), dtype=np.float32)
+        ids = np.empty((nq, k), dtype=np.int64)
+        _check(load().amdr_maxsim_search(self._h, _p(Q, C.c_float), C.c_int32(nq), C.c_int32(q_len), C.c_int32(k),
+                                         _p(scores, C.c_float), _p(ids, C.c_int64)), "amdr_maxsim_search")
+        return scores, ids
+
+    def search_device(self, q_ptr: int, nq: int, q_len: int, k: int, scores_ptr: int, ids_ptr: int,
+                      stream: int = 0) -> None:
+        _check(load().amdr_maxsim_search_device(self._h, _vp(q_ptr), C.c_int32(nq), C.c_int32(q_len), C.c_int32(k),
+                                                _vp(scores_ptr), _vp(ids_ptr), _vp(stream)),
+               "amdr_maxsim_search_device")
+
+    def scores(self, Q: np.ndarray) -> np.ndarray:
+        Q = self._q(Q)
+        nq, q_len = Q.shape[0], Q.shape[1]
+        out = np.empty((nq, self.n_docs), dtype=np.float32)
+        _check(load().amdr_maxsim_scores(self._h, _p(Q, C.c_float), C.c_int32(nq), C.c_int32(q_len),
+                                         _p(out, C.c_float)), "amdr_maxsim_scores")
+        return out
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) and self._h.value:
+            load().amdr_maxsim_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------
+def make_fuse_params(*, method: str = "rrf_norm_blend", rrf_k: int = 60, alpha: float = 0.5, w_dense: float = 0.6,
+                     w_bm25: float = 0.4, w_colbert: float = 0.35, min_final_score: float = -math.inf) -> FuseParams:
+    m = FUSE_METHODS.get(str(method).lower(), 0)  # unknown strings fall to the blend, like the reference's `else`
+    return FuseParams(m, int(rrf_k), float(alpha), float(w_dense), float(w_bm25), float(w_colbert),
+                      float(min_final_score))
+
+
+def _chan(ids, scores, sdtype, nq):
+    if ids is None or scores is None:
+        return None, None, 0
+    ids = _c(ids, np.int64).reshape(nq, -1)
+    scores = _c(scores, sdtype).reshape(nq, -1)
+    assert ids.shape == scores.shape
+    if ids.shape[1] == 0:
+        return None, None, 0
+    return ids, scores, int(ids.shape[1])
+
+
+def fuse(params: FuseParams, nq: int, dense=None, bm25=None, colbert=None):
+    """Host-pointer fusion. Each channel is (ids i64[nq,k], scores[nq,k]) or None.
+    Returns (ids [nq,max_out], vals [nq,max_out,9], mask [nq,max_out], count [nq])."""
+    di, ds, kd = _chan(*(dense or (None, None)), np.float32, nq)
+    bi, bs, kb = _chan(*(bm25 or (None, None)), np.float64, nq)
+    ci, cs, kc = _chan(*(colbert or (None, None)), np.float32, nq)
+    mo = kd + kb + kc
+    out_ids = np.full((nq, max(mo, 1)), -1, dtype=np.int64)
+    out_vals = np.zeros((nq, max(mo, 1), FUSE_NVALS), dtype=np.float64)
+    out_mask = np.zeros((nq, max(mo, 1)), dtype=np.int32)
+    out_count = np.zeros((nq,), dtype=np.int32)
+    if mo == 0 or nq == 0:
+        return out_ids[:, :0], out_vals[:, :0], out_mask[:, :0], out_count
+    _check(load().amdr_fuse(C.byref(params), C.c_int32(nq), _p(di, C.c_int64), _p(ds, C.c_float), C.c_int32(kd),
+                            _p(bi, C.c_int64), _p(bs, C.c_double), C.c_int32(kb), _p(ci, C.c_int64),
+                            _p(cs, C.c_float), C.c_int32(kc), _p(out_ids, C.c_int64), _p(out_vals, C.c_double),
+                            _p(out_mask, C.c_int32), _p(out_count, C.c_int32)), "amdr_fuse")
+    return out_ids, out_vals, out_mask, out_count
+
+
+def fuse_device(params: FuseParams, nq: int, dense, bm25, colbert, out_ids: int, out_vals: int, out_mask: int,
+                out_count: int, *, device: int = 0, stream: int = 0) -> None:
+    """Device-pointer fusion. Each channel = (ids_ptr, scores_ptr, k, row2uid_ptr|0) or None."""
+    def un(c):
+        return c if c is not None else (0, 0, 0, 0)
+    d, b, c = un(dense), un(bm25), un(colbert)
+    _check(load().amdr_fuse_device(C.byref(params), C.c_int32(nq),
+                                   _vp(d[0]), _vp(d[1]), C.c_int32(d[2]), _vp(d[3]),
+                                   _vp(b[0]), _vp(b[1]), C.c_int32(b[2]), _vp(b[3]),
+                                   _vp(c[0]), _vp(c[1]), C.c_int32(c[2]), _vp(c[3]),
+                                   _vp(out_ids), _vp(out_vals), _vp(out_mask), _vp(out_count),
+                                   C.c_int32(device), _vp(stream)), "amdr_fuse_device")
+
+
+def rerank_blend(count: np.ndarray, ids: np.ndarray, vals: np.ndarray, mask: np.ndarray, ce_raw: np.ndarray,
+                 beta: float):
+    """In-place rerank blend on host arrays (copies through the device).
+    ce_raw: [nq, top_n].  Returns out_rerank [nq, max_out, 2] (raw, norm)."""
+    nq, max_out = ids.shape
+    ce_raw = _c(ce_raw, np.float64).reshape(nq, -1)
+    top_n = int(ce_raw.shape[1])
+    out = np.full((nq, max_out, 2), np.nan, dtype=np.float64)
+    assert ids.flags.c_contiguous and vals.flags.c_contiguous and mask.flags.c_contiguous
+    count = _c(count, np.int32)
+    _check(load().amdr_rerank_blend(C.c_int32(nq), C.c_int32(max_out), _p(count, C.c_int32), _p(ids, C.c_int64),
+                                    _p(vals, C.c_double), _p(mask, C.c_int32), _p(ce_raw, C.c_double),
+                                    C.c_int32(top_n), C.c_double(beta), _p(out, C.c_double)), "amdr_rerank_blend")
+    return out
+
+
+def rerank_blend_device(nq: int, max_out: int, count: int, ids: int, vals: int, mask: int, ce_raw: int, top_n: int,
+                        beta: float, out_rerank: int, *, device: int = 0, stream: int = 0) -> None:
+    _check(load().amdr_rerank_blend_device(C.c_int32(nq), C.c_int32(max_out), _vp(count), _vp(ids), _vp(vals),
+                                           _vp(mask), _vp(ce_raw), C.c_int32(top_n), C.c_double(beta),
+                                           _vp(out_rerank), C.c_int32(device), _vp(stream)),
+           "amdr_rerank_blend_device")
+
+
+def merge_topk_device(scores: int, ids: int, n_parts: int, nq: int, k_in: int, k_out: int, out_scores: int,
+                      out_ids: int, *, f64: bool, device: int = 0, stream: int = 0) -> None:
+    fn = load().amdr_merge_topk_f64_device if f64 else load().amdr_merge_topk_f32_device
+    _check(fn(_vp(scores), _vp(ids), C.c_int32(n_parts), C.c_int32(nq), C.c_int32(k_in), C.c_int32(k_out),
+              _vp(out_scores), _vp(out_ids), C.c_int32(device), _vp(stream)), "amdr_merge_topk_device")

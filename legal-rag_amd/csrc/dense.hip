@@ -1,0 +1,497 @@
+// Dense channel: exact inner-product scan + fused top-k for gfx950.
+//
+// Replaces faiss `index.search(q_vec, k)` (legalrag/retrieval/dense_retriever.py:42).
+// The chunk matrix X[n, d] (fp32, row-major) is streamed from HBM exactly once
+// per pass of NQ queries: a wave owns a row at a time, lane l holds the float4
+// pieces at columns 4l + 256c, the NQ query vectors live in registers, and the
+// per-row partial sums are folded with DPP row operations (no LDS round trip).
+// Scores never go to memory: each wave keeps its own top-k staging buffer in
+// LDS (topk.hpp), one list per block is written out and a second small kernel
+// merges the per-block lists.  HBM-bound by construction: algorithmic bytes
+// = n*d*4 per pass, flops = 2*n*d*NQ.
+#include "common.hpp"
+#include "topk.hpp"
+
+#include <cfloat>
+#include <mutex>
+#include <new>
+
+namespace amdr {
+
+// --- wave64 sum via DPP: result valid in lane 63 -----------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+  return v + __int_as_float(t);
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+  v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_add<0x118, 0xf>(v);  // row_shr:8  -> lane 15 of each row = row sum
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1,3
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2,3 -> lane 63 = total
+  return v;
+}
+
+__device__ __forceinline__ float dot4(const float4& a, const float4& b, float acc) {
+  acc = fmaf(a.x, b.x, acc);
+  acc = fmaf(a.y, b.y, acc);
+  acc = fmaf(a.z, b.z, acc);
+  acc = fmaf(a.w, b.w, acc);
+  return acc;
+}
+
+constexpr int kWaves = 4;  // 256-thread blocks
+
+// grid: (x = row slabs, y = query groups of NQ).  LDS: kWaves*NQ*cap C32 + ints.
+template <int NQ, int CH, int U>
+__global__ __launch_bounds__(256) void dense_scan_topk_kernel(const float* __restrict__ X, long n, int d,
+                                                               const float* __restrict__ Q, int nq_total, int k,
+                                                               int cap, long rows_per_block,
+                                                               C32* __restrict__ part /*[gridDim.x][nq_total][k]*/) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  C32* lists = reinterpret_cast<C32*>(smem);
+  int* cnts = reinterpret_cast<int*>(lists + (size_t)kWaves * NQ * cap);
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int qbase = blockIdx.y * NQ;
+
+  float4 q[NQ][CH];
+#pragma unroll
+  for (int b = 0; b < NQ; ++b) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      int col = c * 256 + lane * 4;
+      bool ok = (qbase + b < nq_total) && (col < d);
+      q[b][c] = ok ? *reinterpret_cast<const float4*>(Q + (size_t)(qbase + b) * d + col) : make_float4(0, 0, 0, 0);
+    }
+  }
+
+  WaveTopK<C32> tk[NQ];
+#pragma unroll
+  for (int b = 0; b < NQ; ++b) tk[b].init(lists + ((size_t)b * kWaves + wave) * cap, cap, k);
+
+  const long row_lo = (long)blockIdx.x * rows_per_block;
+  long row_hi = row_lo + rows_per_block;
+  if (row_hi > n) row_hi = n;
+
+  for (long r0 = row_lo + (long)wave * U; r0 < row_hi; r0 += (long)kWaves * U) {
+    float4 x[U][CH];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      long r = r0 + u;
+      if (r >= row_hi) r = row_hi - 1;  // clamp: keeps the loads unconditional
+      const float* xr = X + (size_t)r * d;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        int col = c * 256 + lane * 4;
+        x[u][c] = (col < d) ? *reinterpret_cast<const float4*>(xr + col) : make_float4(0, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long r = r0 + u;
+      const bool rv = r < row_hi;
+#pragma unroll
+      for (int b = 0; b < NQ; ++b) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) acc = dot4(x[u][c], q[b][c], acc);
+        acc = wave_sum_to_lane63(acc);
+        float s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 63));
+        if (rv) tk[b].push_uniform(C32::make(s, (u32)r), lane);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int b = 0; b < NQ; ++b) tk[b].finalize(lane);
+#pragma unroll
+  for (int b = 0; b < NQ; ++b) {
+    block_combine_topk(tk[b], lists + (size_t)b * kWaves * cap, cap, kWaves, wave, lane, cnts);
+    if (wave == 0 && qbase + b < nq_total) {
+      C32* dst = part + ((size_t)blockIdx.x * nq_total + (qbase + b)) * k;
+      for (int j = lane; j < k; j += 64) dst[j] = (j < tk[b].cnt) ? tk[b].buf[j] : C32::pad();
+    }
+    __syncthreads();
+  }
+}
+
+// One block per query: stream the per-block lists, keep the best k, decode.
+__global__ __launch_bounds__(256) void dense_merge_kernel(const C32* __restrict__ part, int nparts, int nq, int k,
+                                                           int cap, float* __restrict__ out_scores,
+                                                           long long* __restrict__ out_ids) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  C32* lists = reinterpret_cast<C32*>(smem);
+  int* cnts = reinterpret_cast<int*>(lists + (size_t)kWaves * cap);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int qi = blockIdx.x;
+  WaveTopK<C32> tk;
+  tk.init(lists + (size_t)wave * cap, cap, k);
+  const long total = (long)nparts * k;
+  for (long base = (long)wave * 64; base < total; base += (long)kWaves * 64) {
+    long i = base + lane;
+    bool v = i < total;
+    C32 c = C32::pad();
+    if (v) {
+      long p = i / k, j = i - p * k;
+      c = part[((size_t)p * nq + qi) * k + j];
+      v = !c.is_pad();
+    }
+    tk.push_lanes(c, v, lane);
+  }
+  tk.finalize(lane);
+  block_combine_topk(tk, lists, cap, kWaves, wave, lane, cnts);
+  if (wave == 0) {
+    for (int j = lane; j < k; j += 64) {
+      bool v = j < tk.cnt;
+      C32 c = v ? tk.buf[j] : C32::pad();
+      out_scores[(size_t)qi * k + j] = v ? c.score() : -FLT_MAX;
+      out_ids[(size_t)qi * k + j] = v ? c.id() : -1ll;
+    }
+  }
+}
+
+// Generic [n_parts, nq, k_in] (score, global id) merge used after the RCCL
+// all-gather of per-shard results.  T = float or double.
+template <class T>
+__global__ __launch_bounds__(256) void merge_parts_kernel(const T* __restrict__ scores,
+                                                           const long long* __restrict__ ids, int nparts, int nq,
+                                                           int k_in, int k_out, int cap, T* __restrict__ out_scores,
+                                                           long long* __restrict__ out_ids) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  C64* lists = reinterpret_cast<C64*>(smem);
+  int* cnts = reinterpret_cast<int*>(lists + (size_t)kWaves * cap);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int qi = blockIdx.x;
+  WaveTopK<C64> tk;
+  tk.init(lists + (size_t)wave * cap, cap, k_out);
+  const long total = (long)nparts * k_in;
+  for (long base = (long)wave * 64; base < total; base += (long)kWaves * 64) {
+    long i = base + lane;
+    bool v = i < total;
+    C64 c = C64::pad();
+    if (v) {
+      long p = i / k_in, j = i - p * k_in;
+      size_t off = ((size_t)p * nq + qi) * k_in + j;
+      long long id = ids[off];
+      v = id >= 0;
+      if (v) c = sizeof(T) == 8 ? C64::make((double)scores[off], id) : C64::make32((float)scores[off], id);
+    }
+    tk.push_lanes(c, v, lane);
+  }
+  tk.finalize(lane);
+  block_combine_topk(tk, lists, cap, kWaves, wave, lane, cnts);
+  if (wave == 0) {
+    for (int j = lane; j < k_out; j += 64) {
+      bool v = j < tk.cnt;
+      C64 c = v ? tk.buf[j] : C64::pad();
+      T s;
+      if (sizeof(T) == 8)
+        s = v ? (T)unord64(c.key) : (T)(-DBL_MAX);
+      else
+        s = v ? (T)unord32((u32)c.key) : (T)(-FLT_MAX);
+      out_scores[(size_t)qi * k_out + j] = s;
+      out_ids[(size_t)qi * k_out + j] = v ? c.idv : -1ll;
+    }
+  }
+}
+
+template <class T>
+int launch_merge_parts(const T* scores, const int64_t* ids, int nparts, int nq, int k_in, int k_out, T* out_scores,
+                       int64_t* out_ids, hipStream_t st) {
+  int cap = topk_cap(k_out);
+  size_t lds = (size_t)kWaves * cap * sizeof(C64) + kWaves * sizeof(int);
+  hipLaunchKernelGGL((merge_parts_kernel<T>), dim3(nq), dim3(256), lds, st, scores, (const long long*)ids, nparts, nq,
+                     k_in, k_out, cap, out_scores, (long long*)out_ids);
+  AMDR_HIP(hipGetLastError());
+  return AMDR_OK;
+}
+template int launch_merge_parts<float>(const float*, const int64_t*, int, int, int, int, float*, int64_t*, hipStream_t);
+template int launch_merge_parts<double>(const double*, const int64_t*, int, int, int, int, double*, int64_t*,
+                                        hipStream_t);
+
+}  // namespace amdr
+
+using namespace amdr;
+
+struct amdr_dense {
+  int device = 0;
+  int64_t n = 0;
+  int64_t cap_rows = 0;
+  int d = 0;
+  float* X = nullptr;
+  bool owns = true;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  DevBuf part, qbuf, sbuf, ibuf;
+};
+
+namespace {
+
+struct ScanPlan {
+  int nq_per_block;  // NQ template
+  int ch;
+  int cap;
+  long rows_per_block;
+  int grid_x, grid_y;
+  size_t lds;
+  size_t part_bytes;
+};
+
+int make_plan(int64_t n, int d, int nq, int k, ScanPlan* p) {
+  p->ch = ceil_div(d, 256);
+  p->cap = topk_cap(k);
+  // queries per pass: as many as fit 64 KiB of LDS staging and the register budget
+  int nqb = 8;
+  while (nqb > 1 && (size_t)kWaves * nqb * p->cap * sizeof(C32) > 60 * 1024) nqb >>= 1;
+  if (p->ch >= 4 && nqb > 4) nqb = 4;  // d = 1024: 8 query vectors would spill
+  while (nqb > 1 && nqb / 2 >= nq) nqb >>= 1;
+  p->nq_per_block = nqb;
+  const int U = (nqb <= 2) ? 4 : 2;
+  long min_rows = (long)kWaves * U * 4;  // at least a few iterations per block
+  long max_blocks = 256L * 8;
+  long gx = (n + min_rows - 1) / min_rows;
+  if (gx > max_blocks) gx = max_blocks;
+  if (gx < 1) gx = 1;
+  p->rows_per_block = (n + gx - 1) / gx;
+  // round the slab to a multiple of the block's row stride so waves stay aligned
+  long stride = (long)kWaves * U;
+  p->rows_per_block = ((p->rows_per_block + stride - 1) / stride) * stride;
+  p->grid_x = (int)((n + p->rows_per_block - 1) / p->rows_per_block);
+  if (p->grid_x < 1) p->grid_x = 1;
+  p->grid_y = ceil_div(nq, nqb);
+  p->lds = (size_t)kWaves * nqb * p->cap * sizeof(C32) + kWaves * sizeof(int);
+  p->part_bytes = (size_t)p->grid_x * nq * k * sizeof(C32);
+  return AMDR_OK;
+}
+
+template <int NQ, int CH>
+void launch_scan(const ScanPlan& p, const amdr_dense* h, const float* Q, int nq, int k, C32* part, hipStream_t st) {
+  constexpr int U = (NQ <= 2) ? 4 : 2;
+  hipLaunchKernelGGL((dense_scan_topk_kernel<NQ, CH, U>), dim3(p.grid_x, p.grid_y), dim3(256), p.lds, st, h->X,
+                     (long)h->n, h->d, Q, nq, k, p.cap, p.rows_per_block, part);
+}
+
+template <int NQ>
+int launch_scan_ch(const ScanPlan& p, const amdr_dense* h, const float* Q, int nq, int k, C32* part, hipStream_t st) {
+  switch (p.ch) {
+    case 1: launch_scan<NQ, 1>(p, h, Q, nq, k, part, st); break;
+    case 2: launch_scan<NQ, 2>(p, h, Q, nq, k, part, st); break;
+    case 3: launch_scan<NQ, 3>(p, h, Q, nq, k, part, st); break;
+    case 4: launch_scan<NQ, 4>(p, h, Q, nq, k, part, st); break;
+    default: return fail(AMDR_EINVAL, "dense: unsupported dim %d", h->d);
+  }
+  return AMDR_OK;
+}
+
+int run_search(amdr_dense* h, const float* Q_dev, int nq, int k, float* scores_dev, int64_t* ids_dev,
+               hipStream_t st) {
+  ScanPlan p;
+  make_plan(h->n, h->d, nq, k, &p);
+  int rc = h->part.ensure(p.part_bytes);
+  if (rc) return rc;
+  C32* part = h->part.as<C32>();
+  if (h->n > 0) {
+    switch (p.nq_per_block) {
+      case 1: rc = launch_scan_ch<1>(p, h, Q_dev, nq, k, part, st); break;
+      case 2: rc = launch_scan_ch<2>(p, h, Q_dev, nq, k, part, st); break;
+      case 4: rc = launch_scan_ch<4>(p, h, Q_dev, nq, k, part, st); break;
+      default: rc = launch_scan_ch<8>(p, h, Q_dev, nq, k, part, st); break;
+    }
+    if (rc) return rc;
+    AMDR_HIP(hipGetLastError());
+  }
+  int nparts = h->n > 0 ? p.grid_x : 0;
+  size_t lds = (size_t)kWaves * p.cap * sizeof(C32) + kWaves * sizeof(int);
+  hipLaunchKernelGGL(dense_merge_kernel, dim3(nq), dim3(256), lds, st, part, nparts, nq, k, p.cap, scores_dev,
+                     (long long*)ids_dev);
+  AMDR_HIP(hipGetLastError());
+  return AMDR_OK;
+}
+
+int check_search_args(const amdr_dense* h, const void* Q, int nq, int k, const void* s, const void* i) {
+  AMDR_REQUIRE(h != nullptr, "dense: null handle");
+  AMDR_REQUIRE(nq >= 0, "dense: nq=%d", nq);
+  AMDR_REQUIRE(k >= 1 && k <= AMDR_MAX_K, "dense: k=%d outside [1,%d]", k, AMDR_MAX_K);
+  AMDR_REQUIRE(nq == 0 || (Q && s && i), "dense: null buffer");
+  return AMDR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int amdr_dense_create(const float* X_host, int64_t n, int32_t d, int32_t device, amdr_dense_t** out) {
+  AMDR_REQUIRE(out != nullptr, "dense_create: out is null");
+  *out = nullptr;
+  AMDR_REQUIRE(n >= 0 && n < (1ll << 32), "dense_create: n=%lld outside [0, 2^32)", (long long)n);
+  AMDR_REQUIRE(d >= 4 && d <= AMDR_MAX_DIM && d % 4 == 0, "dense_create: d=%d must be a multiple of 4 in [4,%d]", d,
+               AMDR_MAX_DIM);
+  AMDR_REQUIRE(n == 0 || X_host != nullptr, "dense_create: X is null");
+  int rc = check_device(device);
+  if (rc) return rc;
+  amdr_dense* h = new (std::nothrow) amdr_dense();
+  if (!h) return fail(AMDR_ENOMEM, "dense_create: host alloc");
+  h->device = device;
+  h->n = n;
+  h->d = d;
+  h->cap_rows = n;
+  hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e == hipSuccess && n > 0) e = hipMalloc((void**)&h->X, (size_t)n * d * sizeof(float));
+  if (e == hipSuccess && n > 0) e = hipMemcpy(h->X, X_host, (size_t)n * d * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    amdr_dense_destroy(h);
+    return fail(e == hipErrorOutOfMemory ? AMDR_ENOMEM : AMDR_EHIP, "dense_create: %s", hipGetErrorString(e));
+  }
+  *out = h;
+  return AMDR_OK;
+}
+
+int amdr_dense_create_from_device(const float* X_dev, int64_t n, int32_t d, int32_t device, amdr_dense_t** out) {
+  AMDR_REQUIRE(out != nullptr, "dense_create_from_device: out is null");
+  *out = nullptr;
+  AMDR_REQUIRE(n >= 0 && n < (1ll << 32), "dense_create_from_device: n=%lld outside [0, 2^32)", (long long)n);
+  AMDR_REQUIRE(d >= 4 && d <= AMDR_MAX_DIM && d % 4 == 0, "dense_create_from_device: bad d=%d", d);
+  AMDR_REQUIRE(n == 0 || X_dev != nullptr, "dense_create_from_device: X is null");
+  AMDR_REQUIRE(((uintptr_t)X_dev & 15) == 0, "dense_create_from_device: X must be 16-byte aligned");
+  int rc = check_device(device);
+  if (rc) return rc;
+  amdr_dense* h = new (std::nothrow) amdr_dense();
+  if (!h) return fail(AMDR_ENOMEM, "dense_create_from_device: host alloc");
+  h->device = device;
+  h->n = n;
+  h->d = d;
+  h->cap_rows = n;
+  h->X = const_cast<float*>(X_dev);
+  h->owns = false;
+  hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    amdr_dense_destroy(h);
+    return fail(AMDR_EHIP, "dense_create_from_device: %s", hipGetErrorString(e));
+  }
+  *out = h;
+  return AMDR_OK;
+}
+
+int amdr_dense_add(amdr_dense_t* h, const float* X_host, int64_t n_add) {
+  AMDR_REQUIRE(h != nullptr, "dense_add: null handle");
+  AMDR_REQUIRE(h->owns, "dense_add: handle wraps caller-owned memory");
+  AMDR_REQUIRE(n_add >= 0 && (n_add == 0 || X_host), "dense_add: bad arguments");
+  AMDR_REQUIRE(h->n + n_add < (1ll << 32), "dense_add: too many rows");
+  std::lock_guard<std::mutex> g(h->mu);
+  AMDR_HIP(hipSetDevice(h->device));
+  if (n_add == 0) return AMDR_OK;
+  if (h->n + n_add > h->cap_rows) {
+    int64_t ncap = h->cap_rows * 2 > h->n + n_add ? h->cap_rows * 2 : h->n + n_add;
+    float* nx = nullptr;
+    AMDR_HIP(hipMalloc((void**)&nx, (size_t)ncap * h->d * sizeof(float)));
+    if (h->n > 0) AMDR_HIP(hipMemcpy(nx, h->X, (size_t)h->n * h->d * sizeof(float), hipMemcpyDeviceToDevice));
+    if (h->X) (void)hipFree(h->X);
+    h->X = nx;
+    h->cap_rows = ncap;
+  }
+  AMDR_HIP(hipMemcpy(h->X + (size_t)h->n * h->d, X_host, (size_t)n_add * h->d * sizeof(float), hipMemcpyHostToDevice));
+  h->n += n_add;
+  return AMDR_OK;
+}
+
+int amdr_dense_ntotal(const amdr_dense_t* h, int64_t* n) {
+  AMDR_REQUIRE(h && n, "dense_ntotal: null");
+  *n = h->n;
+  return AMDR_OK;
+}
+int amdr_dense_dim(const amdr_dense_t* h, int32_t* d) {
+  AMDR_REQUIRE(h && d, "dense_dim: null");
+  *d = h->d;
+  return AMDR_OK;
+}
+
+int amdr_dense_reserve(amdr_dense_t* h, int32_t nq_max, int32_t k_max) {
+  AMDR_REQUIRE(h != nullptr, "dense_reserve: null handle");
+  AMDR_REQUIRE(nq_max >= 1 && k_max >= 1 && k_max <= AMDR_MAX_K, "dense_reserve: bad sizes");
+  std::lock_guard<std::mutex> g(h->mu);
+  AMDR_HIP(hipSetDevice(h->device));
+  ScanPlan p;
+  make_plan(h->n, h->d, nq_max, k_max, &p);
+  int rc = h->part.ensure(p.part_bytes);
+  if (rc) return rc;
+  if ((rc = h->qbuf.ensure((size_t)nq_max * h->d * sizeof(float)))) return rc;
+  if ((rc = h->sbuf.ensure((size_t)nq_max * k_max * sizeof(float)))) return rc;
+  return h->ibuf.ensure((size_t)nq_max * k_max * sizeof(int64_t));
+}
+
+int amdr_dense_search_device(amdr_dense_t* h, const float* Q_dev, int32_t nq, int32_t k, float* scores_dev,
+                             int64_t* ids_dev, void* stream) {
+  int rc = check_search_args(h, Q_dev, nq, k, scores_dev, ids_dev);
+  if (rc) return rc;
+  if (nq == 0) return AMDR_OK;
+  std::lock_guard<std::mutex> g(h->mu);
+  AMDR_HIP(hipSetDevice(h->device));
+  return run_search(h, Q_dev, nq, k, scores_dev, ids_dev, (hipStream_t)stream);
+}
+
+int amdr_dense_search(amdr_dense_t* h, const float* Q_host, int32_t nq, int32_t k, float* scores_host,
+                      int64_t* ids_host) {
+  int rc = check_search_args(h, Q_host, nq, k, scores_host, ids_host);
+  if (rc) return rc;
+  if (nq == 0) return AMDR_OK;
+  std::lock_guard<std::mutex> g(h->mu);
+  AMDR_HIP(hipSetDevice(h->device));
+  if ((rc = h->qbuf.ensure((size_t)nq * h->d * sizeof(float)))) return rc;
+  if ((rc = h->sbuf.ensure((size_t)nq * k * sizeof(float)))) return rc;
+  if ((rc = h->ibuf.ensure((size_t)nq * k * sizeof(int64_t)))) return rc;
+  AMDR_HIP(hipMemcpyAsync(h->qbuf.p, Q_host, (size_t)nq * h->d * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  rc = run_search(h, h->qbuf.as<float>(), nq, k, h->sbuf.as<float>(), h->ibuf.as<int64_t>(), h->stream);
+  if (rc) return rc;
+  AMDR_HIP(hipMemcpyAsync(scores_host, h->sbuf.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  AMDR_HIP(hipMemcpyAsync(ids_host, h->ibuf.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+  AMDR_HIP(hipStreamSynchronize(h->stream));
+  return AMDR_OK;
+}
+
+int amdr_dense_read_rows(const amdr_dense_t* h, int64_t row0, int64_t nrows, float* out_host) {
+  AMDR_REQUIRE(h && out_host, "dense_read_rows: null");
+  AMDR_REQUIRE(row0 >= 0 && nrows >= 0 && row0 + nrows <= h->n, "dense_read_rows: range outside [0,%lld)",
+               (long long)h->n);
+  AMDR_HIP(hipSetDevice(h->device));
+  if (nrows)
+    AMDR_HIP(hipMemcpy(out_host, h->X + (size_t)row0 * h->d, (size_t)nrows * h->d * sizeof(float),
+                       hipMemcpyDeviceToHost));
+  return AMDR_OK;
+}
+
+int amdr_dense_destroy(amdr_dense_t* h) {
+  if (!h) return AMDR_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) {
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipStreamDestroy(h->stream);
+  }
+  if (h->owns && h->X) (void)hipFree(h->X);
+  h->part.release();
+  h->qbuf.release();
+  h->sbuf.release();
+  h->ibuf.release();
+  delete h;
+  return AMDR_OK;
+}
+
+int amdr_merge_topk_f32_device(const float* scores, const int64_t* ids, int32_t n_parts, int32_t nq, int32_t k_in,
+                               int32_t k_out, float* out_scores, int64_t* out_ids, int32_t device, void* stream) {
+  AMDR_REQUIRE(scores && ids && out_scores && out_ids, "merge_topk: null buffer");
+  AMDR_REQUIRE(n_parts >= 1 && nq >= 1 && k_in >= 1 && k_out >= 1 && k_out <= AMDR_MAX_K, "merge_topk: bad sizes");
+  AMDR_HIP(hipSetDevice(device));
+  return launch_merge_parts<float>(scores, ids, n_parts, nq, k_in, k_out, out_scores, out_ids, (hipStream_t)stream);
+}
+int amdr_merge_topk_f64_device(const double* scores, const int64_t* ids, int32_t n_parts, int32_t nq, int32_t k_in,
+                               int32_t k_out, double* out_scores, int64_t* out_ids, int32_t device, void* stream) {
+  AMDR_REQUIRE(scores && ids && out_scores && out_ids, "merge_topk: null buffer");
+  AMDR_REQUIRE(n_parts >= 1 && nq >= 1 && k_in >= 1 && k_out >= 1 && k_out <= AMDR_MAX_K, "merge_topk: bad sizes");
+  AMDR_HIP(hipSetDevice(device));
+  return launch_merge_parts<double>(scores, ids, n_parts, nq, k_in, k_out, out_scores, out_ids, (hipStream_t)stream);
+}
+
+}  // extern "C"

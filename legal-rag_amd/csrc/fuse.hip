@@ -1,0 +1,460 @@
+// Fusion + min_final filter + rerank blend, on device, fp64, no FMA contraction.
+//
+// Replaces HybridRetriever._fuse (legalrag/retrieval/hybrid_retriever.py:389-551),
+// _minmax (:24-30), _rrf_with_breakdown (:33-56), the min_final_score filter
+// (:309-310) and the rerank blend (:338-355, rerankers.py:48-54,349).
+// One wave per query; the candidate set is at most kd+kb+kc (<= 768) ids, so
+// this is latency work: the point of doing it on the GPU is that a batch of
+// queries never leaves HBM between the channel kernels and the final top-k.
+// Every expression below is written in the reference's operand order and this
+// file is compiled with -ffp-contract=off so results are bit-identical to the
+// Python float arithmetic.  Exactly tied scores keep first-appearance order.
+#include "common.hpp"
+
+#include <cfloat>
+#include <cmath>
+
+namespace amdr {
+
+constexpr int kFuseMax = 3 * AMDR_MAX_K;  // 768
+
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ void lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+struct ChanIn {
+  const long long* ids;  // [nq, k]
+  const void* scores;    // float or double [nq, k]
+  const long long* row2uid;
+  int k;
+  int is_f64;
+};
+
+__device__ __forceinline__ double chan_score(const ChanIn& c, int qi, int j) {
+  size_t off = (size_t)qi * c.k + j;
+  return c.is_f64 ? ((const double*)c.scores)[off] : (double)((const float*)c.scores)[off];
+}
+__device__ __forceinline__ long long chan_uid(const ChanIn& c, int qi, int j) {
+  long long id = c.ids[(size_t)qi * c.k + j];
+  if (id >= 0 && c.row2uid) id = c.row2uid[id];
+  return id;
+}
+
+// block = 64 threads (one wave); grid = nq
+__global__ __launch_bounds__(64) void fuse_kernel(amdr_fuse_params_t P, ChanIn c0, ChanIn c1, ChanIn c2, int max_out,
+                                                  long long* __restrict__ out_ids, double* __restrict__ out_vals,
+                                                  int* __restrict__ out_mask, int* __restrict__ out_count) {
+  __shared__ long long uid[kFuseMax];
+  __shared__ int pos[3][kFuseMax];
+  __shared__ double sc[kFuseMax];
+  __shared__ double tot[kFuseMax];
+  const int lane = threadIdx.x;
+  const int qi = blockIdx.x;
+  const ChanIn ch[3] = {c0, c1, c2};
+  const double w[3] = {P.w_dense, P.w_bm25, P.w_colbert};
+
+  // ---- valid prefix length, min / max of every channel ------------------
+  int n[3];
+  double lo[3], hi[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    int cnt = 0;
+    double mn = INFINITY, mx = -INFINITY;
+    for (int j = lane; j < ch[c].k; j += 64) {
+      if (ch[c].ids[(size_t)qi * ch[c].k + j] >= 0) {
+        cnt++;
+        double s = chan_score(ch[c], qi, j);
+        mn = fmin(mn, s);
+        mx = fmax(mx, s);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    n[c] = cnt;
+    lo[c] = wave_min(mn);
+    hi[c] = wave_max(mx);
+  }
+
+  // ---- union of ids in first-appearance order ----------------------------
+  int U = 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int U0 = U;  // entries a new id can collide with (ids are unique inside a channel)
+    for (int base = 0; base < n[c]; base += 64) {
+      const int j = base + lane;
+      const bool v = j < n[c];
+      long long my = v ? chan_uid(ch[c], qi, j) : -1;
+      int f = -1;
+      if (v)
+        for (int u = 0; u < U0; ++u)
+          if (uid[u] == my) {
+            f = u;
+            break;
+          }
+      const bool isnew = v && f < 0;
+      const unsigned long long m = __ballot(isnew);
+      const unsigned long long lt = (lane == 0) ? 0ull : (m & (~0ull >> (64 - lane)));
+      const int idx = isnew ? U + __popcll(lt) : f;
+      if (isnew) {
+        uid[idx] = my;
+        pos[0][idx] = -1;
+        pos[1][idx] = -1;
+        pos[2][idx] = -1;
+      }
+      lds_sync();
+      if (v) pos[c][idx] = j;
+      U += __popcll(m);
+      lds_sync();
+    }
+  }
+
+  // ---- RRF totals, their min / max ---------------------------------------
+  const bool wrrf = (P.method == AMDR_FUSE_WRRF);
+  double rmn = INFINITY, rmx = -INFINITY;
+  for (int u = lane; u < U; u += 64) {
+    double t = 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      int p = pos[c][u];
+      if (p >= 0) {
+        double wc = wrrf ? w[c] : 1.0;
+        double v = wc * (1.0 / (double)(P.rrf_k + p + 1));
+        t = t + v;
+      }
+    }
+    tot[u] = t;
+    rmn = fmin(rmn, t);
+    rmx = fmax(rmx, t);
+  }
+  rmn = wave_min(rmn);
+  rmx = wave_max(rmx);
+  const bool rdeg = (rmx - rmn < 1e-12);
+
+  // all values of candidate u; evaluated twice (score pass, output pass) so that
+  // nothing but the score has to live across the rank computation
+  auto eval = [&](int u, double (&val)[AMDR_FUSE_NVALS], int& mk) {
+    const double t = tot[u];
+    const double rrf_norm = rdeg ? 0.0 : (t - rmn) / (rmx - rmn);
+    double nrm[3], raw[3], wt[3];
+    mk = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      int p = pos[c][u];
+      nrm[c] = 0.0;
+      raw[c] = 0.0;
+      if (p >= 0) {
+        mk |= (1 << c);
+        double s = chan_score(ch[c], qi, p);
+        nrm[c] = (hi[c] - lo[c] < 1e-12) ? 0.0 : (s - lo[c]) / (hi[c] - lo[c]);
+        double wc = wrrf ? w[c] : 1.0;
+        raw[c] = wc * (1.0 / (double)(P.rrf_k + p + 1));
+      }
+      wt[c] = w[c] * nrm[c];
+    }
+    const double wsum = (wt[0] + wt[1]) + wt[2];
+    double score, con[3] = {0.0, 0.0, 0.0};
+    if (P.method == AMDR_FUSE_WEIGHTED_SUM) {
+      score = wsum;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) con[c] = wt[c];
+    } else if (P.method == AMDR_FUSE_RRF || P.method == AMDR_FUSE_WRRF) {
+      score = rrf_norm;
+      const double mass = score;
+      if (!(mass <= 0.0 || t <= 1e-18)) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          if (pos[c][u] >= 0) con[c] = mass * raw[c] / t;
+      }
+    } else {
+      score = P.alpha * rrf_norm + (1.0 - P.alpha) * wsum;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) con[c] = 0.0 + (1.0 - P.alpha) * wt[c];
+      const double mass = P.alpha * rrf_norm;
+      if (!(mass <= 0.0 || t <= 1e-18)) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          if (pos[c][u] >= 0) con[c] = con[c] + mass * raw[c] / t;
+      }
+    }
+    val[AMDR_FV_SCORE] = score;
+    val[AMDR_FV_RRF_NORM] = rrf_norm;
+    val[AMDR_FV_WSUM] = wsum;
+    val[AMDR_FV_NORM_DENSE] = nrm[0];
+    val[AMDR_FV_NORM_BM25] = nrm[1];
+    val[AMDR_FV_NORM_COLBERT] = nrm[2];
+    val[AMDR_FV_CONTRIB_DENSE] = con[0];
+    val[AMDR_FV_CONTRIB_BM25] = con[1];
+    val[AMDR_FV_CONTRIB_COLBERT] = con[2];
+  };
+
+  for (int u = lane; u < U; u += 64) {
+    double val[AMDR_FUSE_NVALS];
+    int mk;
+    eval(u, val, mk);
+    sc[u] = val[AMDR_FV_SCORE];
+  }
+  lds_sync();
+
+  // ---- stable descending rank, filter, scatter ---------------------------
+  int kept = 0;
+  const size_t obase = (size_t)qi * max_out;
+  for (int u = lane; u < U; u += 64) {
+    double val[AMDR_FUSE_NVALS];
+    int mk;
+    eval(u, val, mk);
+    const double s = val[AMDR_FV_SCORE];
+    int r = 0;
+    for (int v2 = 0; v2 < U; ++v2) {
+      const double o = sc[v2];
+      r += (o > s) || (o == s && v2 < u);
+    }
+    if (s >= P.min_final_score) kept++;
+    out_ids[obase + r] = uid[u];
+    out_mask[obase + r] = mk;
+#pragma unroll
+    for (int x = 0; x < AMDR_FUSE_NVALS; ++x) out_vals[(obase + r) * AMDR_FUSE_NVALS + x] = val[x];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o);
+  for (int r = U + lane; r < max_out; r += 64) {
+    out_ids[obase + r] = -1;
+    out_mask[obase + r] = 0;
+    for (int x = 0; x < AMDR_FUSE_NVALS; ++x) out_vals[(obase + r) * AMDR_FUSE_NVALS + x] = 0.0;
+  }
+  if (lane == 0) out_count[qi] = kept;
+}
+
+// block = 64 threads; grid = nq.  Dynamic LDS: staging for one query's lists.
+__global__ __launch_bounds__(64) void rerank_blend_kernel(int max_out, const int* __restrict__ count,
+                                                          long long* __restrict__ ids, double* __restrict__ vals,
+                                                          int* __restrict__ mask, const double* __restrict__ ce_raw,
+                                                          int top_n, double beta, double* __restrict__ out_rerank) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* svals = reinterpret_cast<double*>(smem);                   // [max_out][NVALS]
+  double* snew = svals + (size_t)max_out * AMDR_FUSE_NVALS;            // new score per input position
+  double* snorm = snew + max_out;                                    // norm per candidate
+  long long* sids = reinterpret_cast<long long*>(snorm + max_out);   // [max_out]
+  int* smask = reinterpret_cast<int*>(sids + max_out);               // [max_out]
+  int* spre = smask + max_out;                                       // position in the pre-sort sequence
+  const int lane = threadIdx.x, qi = blockIdx.x;
+  const size_t base = (size_t)qi * max_out;
+  const int cnt = count[qi];
+  const int n = cnt < top_n ? cnt : top_n;
+  const double nan = __longlong_as_double(0x7ff8000000000000ll);
+
+  for (int r = lane; r < max_out; r += 64) {
+    out_rerank[(base + r) * 2 + 0] = nan;
+    out_rerank[(base + r) * 2 + 1] = nan;
+  }
+  if (n <= 0) return;
+
+  double mn = INFINITY, mx = -INFINITY;
+  for (int j = lane; j < n; j += 64) {
+    double r = ce_raw[(size_t)qi * top_n + j];
+    mn = fmin(mn, r);
+    mx = fmax(mx, r);
+  }
+  mn = wave_min(mn);
+  mx = wave_max(mx);
+  const bool deg = (mx - mn < 1e-12);
+
+  for (int j = lane; j < cnt; j += 64) {
+    for (int x = 0; x < AMDR_FUSE_NVALS; ++x) svals[(size_t)j * AMDR_FUSE_NVALS + x] = vals[(base + j) * AMDR_FUSE_NVALS + x];
+    sids[j] = ids[base + j];
+    smask[j] = mask[base + j];
+    double s = svals[(size_t)j * AMDR_FUSE_NVALS + AMDR_FV_SCORE];
+    if (j < n) {
+      double raw = ce_raw[(size_t)qi * top_n + j];
+      double nm = deg ? 0.0 : (raw - mn) / (mx - mn);
+      snorm[j] = nm;
+      s = (1 - beta) * s + beta * nm;
+    }
+    snew[j] = s;
+  }
+  lds_sync();
+  // pre-sort sequence: candidates by norm desc (stable), then the untouched tail
+  for (int j = lane; j < cnt; j += 64) {
+    int p = j;
+    if (j < n) {
+      const double nm = snorm[j];
+      p = 0;
+      for (int i = 0; i < n; ++i) {
+        const double o = snorm[i];
+        p += (o > nm) || (o == nm && i < j);
+      }
+    }
+    spre[j] = p;
+  }
+  lds_sync();
+  for (int j = lane; j < cnt; j += 64) {
+    const double s = snew[j];
+    const int pj = spre[j];
+    int r = 0;
+    for (int i = 0; i < cnt; ++i) {
+      const double o = snew[i];
+      r += (o > s) || (o == s && spre[i] < pj);
+    }
+    ids[base + r] = sids[j];
+    mask[base + r] = smask[j];
+    for (int x = 0; x < AMDR_FUSE_NVALS; ++x) vals[(base + r) * AMDR_FUSE_NVALS + x] = svals[(size_t)j * AMDR_FUSE_NVALS + x];
+    vals[(base + r) * AMDR_FUSE_NVALS + AMDR_FV_SCORE] = s;
+    if (j < n) {
+      out_rerank[(base + r) * 2 + 0] = ce_raw[(size_t)qi * top_n + j];
+      out_rerank[(base + r) * 2 + 1] = snorm[j];
+    }
+  }
+}
+
+static size_t rerank_lds(int max_out) {
+  return (size_t)max_out * (AMDR_FUSE_NVALS + 2) * sizeof(double) + (size_t)max_out * sizeof(long long) +
+         (size_t)max_out * 2 * sizeof(int);
+}
+
+}  // namespace amdr
+
+using namespace amdr;
+
+namespace {
+
+int fuse_check(const amdr_fuse_params_t* p, int nq, int kd, int kb, int kc) {
+  AMDR_REQUIRE(p != nullptr, "fuse: null params");
+  AMDR_REQUIRE(p->method >= 0 && p->method <= 3, "fuse: unknown method %d", p->method);
+  AMDR_REQUIRE(nq >= 0, "fuse: nq=%d", nq);
+  AMDR_REQUIRE(kd >= 0 && kd <= AMDR_MAX_K && kb >= 0 && kb <= AMDR_MAX_K && kc >= 0 && kc <= AMDR_MAX_K,
+               "fuse: channel depth outside [0,%d]", AMDR_MAX_K);
+  AMDR_REQUIRE(kd + kb + kc >= 1, "fuse: all channels empty (max_out would be 0)");
+  return AMDR_OK;
+}
+
+}  // namespace
+
+// ---- host-pointer conveniences (single-query API path) ---------------------
+namespace {
+struct Tmp {
+  void* p = nullptr;
+  ~Tmp() {
+    if (p) (void)hipFree(p);
+  }
+};
+template <class T>
+int to_dev(Tmp& t, const T* src, size_t count, hipStream_t st) {
+  if (!count) return AMDR_OK;
+  AMDR_HIP(hipMalloc(&t.p, count * sizeof(T)));
+  if (src) AMDR_HIP(hipMemcpyAsync(t.p, src, count * sizeof(T), hipMemcpyHostToDevice, st));
+  return AMDR_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int amdr_fuse_device(const amdr_fuse_params_t* p, int32_t nq, const int64_t* dense_ids, const float* dense_scores,
+                     int32_t kd, const int64_t* dense_row2uid, const int64_t* bm25_ids, const double* bm25_scores,
+                     int32_t kb, const int64_t* bm25_row2uid, const int64_t* colbert_ids, const float* colbert_scores,
+                     int32_t kc, const int64_t* colbert_row2uid, int64_t* out_ids, double* out_vals,
+                     int32_t* out_mask, int32_t* out_count, int32_t device, void* stream) {
+  int rc = fuse_check(p, nq, kd, kb, kc);
+  if (rc) return rc;
+  AMDR_REQUIRE((kd == 0 || (dense_ids && dense_scores)) && (kb == 0 || (bm25_ids && bm25_scores)) &&
+                   (kc == 0 || (colbert_ids && colbert_scores)),
+               "fuse: null channel buffer");
+  AMDR_REQUIRE(nq == 0 || (out_ids && out_vals && out_mask && out_count), "fuse: null output");
+  if (nq == 0) return AMDR_OK;
+  AMDR_HIP(hipSetDevice(device));
+  ChanIn c0{(const long long*)dense_ids, dense_scores, (const long long*)dense_row2uid, kd, 0};
+  ChanIn c1{(const long long*)bm25_ids, bm25_scores, (const long long*)bm25_row2uid, kb, 1};
+  ChanIn c2{(const long long*)colbert_ids, colbert_scores, (const long long*)colbert_row2uid, kc, 0};
+  hipLaunchKernelGGL(fuse_kernel, dim3(nq), dim3(64), 0, (hipStream_t)stream, *p, c0, c1, c2, kd + kb + kc,
+                     (long long*)out_ids, out_vals, out_mask, out_count);
+  AMDR_HIP(hipGetLastError());
+  return AMDR_OK;
+}
+
+int amdr_rerank_blend_device(int32_t nq, int32_t max_out, const int32_t* count, int64_t* ids, double* vals,
+                             int32_t* mask, const double* ce_raw, int32_t top_n, double beta, double* out_rerank,
+                             int32_t device, void* stream) {
+  AMDR_REQUIRE(nq >= 0 && max_out >= 1 && max_out <= kFuseMax, "rerank_blend: bad sizes");
+  AMDR_REQUIRE(top_n >= 1, "rerank_blend: top_n=%d", top_n);
+  AMDR_REQUIRE(nq == 0 || (count && ids && vals && mask && ce_raw && out_rerank), "rerank_blend: null buffer");
+  if (nq == 0) return AMDR_OK;
+  AMDR_HIP(hipSetDevice(device));
+  size_t lds = rerank_lds(max_out);
+  if (lds > 48 * 1024)
+    AMDR_HIP(hipFuncSetAttribute((const void*)rerank_blend_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(rerank_blend_kernel, dim3(nq), dim3(64), lds, (hipStream_t)stream, max_out, count,
+                     (long long*)ids, vals, mask, ce_raw, top_n, beta, out_rerank);
+  AMDR_HIP(hipGetLastError());
+  return AMDR_OK;
+}
+
+int amdr_fuse(const amdr_fuse_params_t* p, int32_t nq, const int64_t* dense_ids, const float* dense_scores, int32_t kd,
+              const int64_t* bm25_ids, const double* bm25_scores, int32_t kb, const int64_t* colbert_ids,
+              const float* colbert_scores, int32_t kc, int64_t* out_ids, double* out_vals, int32_t* out_mask,
+              int32_t* out_count) {
+  int rc = fuse_check(p, nq, kd, kb, kc);
+  if (rc) return rc;
+  if (nq == 0) return AMDR_OK;
+  int dev = 0;
+  AMDR_HIP(hipGetDevice(&dev));
+  const int mo = kd + kb + kc;
+  Tmp di, ds, bi, bs, ci, cs, oi, ov, om, oc;
+  hipStream_t st = nullptr;
+  if ((rc = to_dev(di, dense_ids, (size_t)nq * kd, st))) return rc;
+  if ((rc = to_dev(ds, dense_scores, (size_t)nq * kd, st))) return rc;
+  if ((rc = to_dev(bi, bm25_ids, (size_t)nq * kb, st))) return rc;
+  if ((rc = to_dev(bs, bm25_scores, (size_t)nq * kb, st))) return rc;
+  if ((rc = to_dev(ci, colbert_ids, (size_t)nq * kc, st))) return rc;
+  if ((rc = to_dev(cs, colbert_scores, (size_t)nq * kc, st))) return rc;
+  if ((rc = to_dev(oi, (const int64_t*)nullptr, (size_t)nq * mo, st))) return rc;
+  if ((rc = to_dev(ov, (const double*)nullptr, (size_t)nq * mo * AMDR_FUSE_NVALS, st))) return rc;
+  if ((rc = to_dev(om, (const int32_t*)nullptr, (size_t)nq * mo, st))) return rc;
+  if ((rc = to_dev(oc, (const int32_t*)nullptr, (size_t)nq, st))) return rc;
+  rc = amdr_fuse_device(p, nq, (const int64_t*)di.p, (const float*)ds.p, kd, nullptr, (const int64_t*)bi.p,
+                        (const double*)bs.p, kb, nullptr, (const int64_t*)ci.p, (const float*)cs.p, kc, nullptr,
+                        (int64_t*)oi.p, (double*)ov.p, (int32_t*)om.p, (int32_t*)oc.p, dev, st);
+  if (rc) return rc;
+  AMDR_HIP(hipMemcpyAsync(out_ids, oi.p, (size_t)nq * mo * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  AMDR_HIP(hipMemcpyAsync(out_vals, ov.p, (size_t)nq * mo * AMDR_FUSE_NVALS * sizeof(double), hipMemcpyDeviceToHost, st));
+  AMDR_HIP(hipMemcpyAsync(out_mask, om.p, (size_t)nq * mo * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  AMDR_HIP(hipMemcpyAsync(out_count, oc.p, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  AMDR_HIP(hipStreamSynchronize(st));
+  return AMDR_OK;
+}
+
+int amdr_rerank_blend(int32_t nq, int32_t max_out, const int32_t* count, int64_t* ids, double* vals, int32_t* mask,
+                      const double* ce_raw, int32_t top_n, double beta, double* out_rerank) {
+  AMDR_REQUIRE(nq >= 0 && max_out >= 1 && max_out <= kFuseMax && top_n >= 1, "rerank_blend: bad sizes");
+  if (nq == 0) return AMDR_OK;
+  AMDR_REQUIRE(count && ids && vals && mask && ce_raw && out_rerank, "rerank_blend: null buffer");
+  int dev = 0, rc;
+  AMDR_HIP(hipGetDevice(&dev));
+  Tmp dc, di, dv, dm, dr, dout;
+  hipStream_t st = nullptr;
+  if ((rc = to_dev(dc, count, (size_t)nq, st))) return rc;
+  if ((rc = to_dev(di, ids, (size_t)nq * max_out, st))) return rc;
+  if ((rc = to_dev(dv, vals, (size_t)nq * max_out * AMDR_FUSE_NVALS, st))) return rc;
+  if ((rc = to_dev(dm, mask, (size_t)nq * max_out, st))) return rc;
+  if ((rc = to_dev(dr, ce_raw, (size_t)nq * top_n, st))) return rc;
+  if ((rc = to_dev(dout, (const double*)nullptr, (size_t)nq * max_out * 2, st))) return rc;
+  rc = amdr_rerank_blend_device(nq, max_out, (const int32_t*)dc.p, (int64_t*)di.p, (double*)dv.p, (int32_t*)dm.p,
+                                (const double*)dr.p, top_n, beta, (double*)dout.p, dev, st);
+  if (rc) return rc;
+  AMDR_HIP(hipMemcpyAsync(ids, di.p, (size_t)nq * max_out * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  AMDR_HIP(hipMemcpyAsync(vals, dv.p, (size_t)nq * max_out * AMDR_FUSE_NVALS * sizeof(double), hipMemcpyDeviceToHost, st));
+  AMDR_HIP(hipMemcpyAsync(mask, dm.p, (size_t)nq * max_out * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  AMDR_HIP(hipMemcpyAsync(out_rerank, dout.p, (size_t)nq * max_out * 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+  AMDR_HIP(hipStreamSynchronize(st));
+  return AMDR_OK;
+}
+
+}  // extern "C"

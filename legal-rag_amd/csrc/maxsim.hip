@@ -1,0 +1,303 @@
+// ColBERT channel: exhaustive late-interaction MaxSim for gfx950.
+//
+// Replaces `Searcher.search(query, k)` (legalrag/retrieval/colbert_retriever.py:152):
+//   score(q, doc) = sum_{i < q_len} max_{j < len(doc)} <q_i, d_j>,  dim = 128, fp32.
+// One wave scores one (query, document) pair.  The 32 x len similarity tile is
+// a genuine small matrix product, so it runs on the matrix cores with the
+// fp32-input v_mfma_f32_32x32x2_f32 (bit-for-bit an fp32 fmaf chain, i.e. the
+// same arithmetic as a VALU dot product, at the same peak rate, but with no
+// cross-lane reduction and no LDS broadcast traffic):
+//   A (32 tokens x 2)  : lane (j = l&31, h = l>>5) holds D[tok0 + j][64h + kk]
+//   B (2 x 32 q-tokens): lane (i = l&31, h = l>>5) holds Q[i][64h + kk]
+// i.e. the k index is permuted so that every lane reads ONE contiguous 256-byte
+// half row; a dot product does not care about the order of its terms as long as
+// A and B agree.  C[token][q-token] comes back with the q-token on the lane and
+// 16 tokens in the lane's registers, so max-over-tokens is in-register and the
+// final sum over q-tokens is one DPP reduction per document.
+// Algorithmic bytes per (query, shard): sum_docs len*128*4; flops 2*32*128*sum len.
+#include "common.hpp"
+#include "topk.hpp"
+
+#include <cfloat>
+#include <mutex>
+#include <new>
+
+namespace amdr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kMsWaves = 4;
+constexpr int kDim = AMDR_MAXSIM_DIM;  // 128
+constexpr int kHalf = kDim / 2;        // 64 floats per lane
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float ms_dpp_add(float v) {
+  int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+  return v + __int_as_float(t);
+}
+__device__ __forceinline__ float ms_wave_sum(float v) {  // total in lane 63
+  v = ms_dpp_add<0x111, 0xf>(v);
+  v = ms_dpp_add<0x112, 0xf>(v);
+  v = ms_dpp_add<0x114, 0xf>(v);
+  v = ms_dpp_add<0x118, 0xf>(v);
+  v = ms_dpp_add<0x142, 0xa>(v);
+  v = ms_dpp_add<0x143, 0xc>(v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+__device__ __forceinline__ void load_half_row(const float* __restrict__ p, float (&r)[kHalf]) {
+#pragma unroll
+  for (int m = 0; m < kHalf / 4; ++m) {
+    float4 v = *reinterpret_cast<const float4*>(p + 4 * m);
+    r[4 * m + 0] = v.x;
+    r[4 * m + 1] = v.y;
+    r[4 * m + 2] = v.z;
+    r[4 * m + 3] = v.w;
+  }
+}
+
+// grid: (x = ceil(n_docs / 4), y = queries); one wave per document.
+__global__ __launch_bounds__(256) void maxsim_scores_kernel(const float* __restrict__ D,
+                                                             const long long* __restrict__ doc_ptr, long n_docs,
+                                                             const float* __restrict__ Q, int q_len,
+                                                             float* __restrict__ scores /*[nq, n_docs]*/) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long doc = (long)blockIdx.x * kMsWaves + wave;
+  if (doc >= n_docs) return;  // whole wave exits together
+  const int qi = blockIdx.y;
+  const int r = lane & 31, h = lane >> 5;
+
+  float qreg[kHalf];
+  if (r < q_len) {
+    load_half_row(Q + ((size_t)qi * q_len + r) * kDim + h * kHalf, qreg);
+  } else {
+#pragma unroll
+    for (int m = 0; m < kHalf; ++m) qreg[m] = 0.f;
+  }
+
+  const long t_lo = doc_ptr[doc], t_hi = doc_ptr[doc + 1];
+  const int len = (int)(t_hi - t_lo);
+  float best = -FLT_MAX;  // running max over this lane's token rows, for q-token r
+
+  for (int tok0 = 0; tok0 < len; tok0 += 32) {
+    int j = tok0 + r;
+    if (j >= len) j = len - 1;  // clamp: rows past the end are masked below
+    float areg[kHalf];
+    load_half_row(D + (size_t)(t_lo + j) * kDim + h * kHalf, areg);
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < kHalf; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[kk], qreg[kk], acc, 0, 0, 0);
+    const int remain = len - tok0;  // valid token rows in this tile (wave-uniform)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int row = (g & 3) + 8 * (g >> 2) + 4 * h;  // C/D map of the 32x32 MFMA
+      float v = acc[g];
+      if (remain < 32 && row >= remain) v = -FLT_MAX;
+      best = fmaxf(best, v);
+    }
+  }
+  // the other half of the wave holds the complementary token rows of the same q-token
+  float other = __shfl_xor(best, 32);
+  best = fmaxf(best, other);
+  float contrib = (h == 0 && r < q_len) ? best : 0.f;
+  float total = ms_wave_sum(contrib);
+  if (lane == 0) scores[(size_t)qi * n_docs + doc] = total;
+}
+
+// Per-query top-k over a dense fp32 score row (one block per query).
+__global__ __launch_bounds__(256) void rowscores_topk_kernel(const float* __restrict__ scores, long n, int k, int cap,
+                                                              float* __restrict__ out_scores,
+                                                              long long* __restrict__ out_ids) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  C32* lists = reinterpret_cast<C32*>(smem);
+  int* cnts = reinterpret_cast<int*>(lists + (size_t)kMsWaves * cap);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int qi = blockIdx.x;
+  const float* row = scores + (size_t)qi * n;
+  WaveTopK<C32> tk;
+  tk.init(lists + (size_t)wave * cap, cap, k);
+  for (long base = (long)wave * 64; base < n; base += (long)kMsWaves * 64) {
+    long i = base + lane;
+    bool v = i < n;
+    C32 c = v ? C32::make(row[i], (u32)i) : C32::pad();
+    tk.push_lanes(c, v, lane);
+  }
+  tk.finalize(lane);
+  block_combine_topk(tk, lists, cap, kMsWaves, wave, lane, cnts);
+  if (wave == 0) {
+    for (int j = lane; j < k; j += 64) {
+      bool v = j < tk.cnt;
+      C32 c = v ? tk.buf[j] : C32::pad();
+      out_scores[(size_t)qi * k + j] = v ? c.score() : -FLT_MAX;
+      out_ids[(size_t)qi * k + j] = v ? c.id() : -1ll;
+    }
+  }
+}
+
+}  // namespace amdr
+
+using namespace amdr;
+
+struct amdr_maxsim {
+  int device = 0;
+  int64_t n_docs = 0, n_tokens = 0;
+  float* D = nullptr;
+  long long* doc_ptr = nullptr;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  DevBuf full, qbuf, sbuf, ibuf;
+};
+
+namespace {
+
+int ms_run(amdr_maxsim* h, const float* Q_dev, int nq, int q_len, int k, float* full_dev, float* scores_dev,
+           int64_t* ids_dev, hipStream_t st) {
+  dim3 grid(ceil_div(h->n_docs, kMsWaves), nq);
+  hipLaunchKernelGGL(maxsim_scores_kernel, grid, dim3(256), 0, st, h->D, h->doc_ptr, (long)h->n_docs, Q_dev, q_len,
+                     full_dev);
+  AMDR_HIP(hipGetLastError());
+  if (scores_dev) {
+    int cap = topk_cap(k);
+    size_t lds = (size_t)kMsWaves * cap * sizeof(C32) + kMsWaves * sizeof(int);
+    hipLaunchKernelGGL(rowscores_topk_kernel, dim3(nq), dim3(256), lds, st, full_dev, (long)h->n_docs, k, cap,
+                       scores_dev, (long long*)ids_dev);
+    AMDR_HIP(hipGetLastError());
+  }
+  return AMDR_OK;
+}
+
+int ms_check(const amdr_maxsim* h, const void* Q, int nq, int q_len, int k) {
+  AMDR_REQUIRE(h != nullptr, "maxsim: null handle");
+  AMDR_REQUIRE(nq >= 0, "maxsim: nq=%d", nq);
+  AMDR_REQUIRE(q_len >= 1 && q_len <= AMDR_MAXSIM_QLEN, "maxsim: q_len=%d outside [1,%d]", q_len, AMDR_MAXSIM_QLEN);
+  AMDR_REQUIRE(k >= 1 && k <= AMDR_MAX_K, "maxsim: k=%d outside [1,%d]", k, AMDR_MAX_K);
+  AMDR_REQUIRE(nq == 0 || Q, "maxsim: null Q");
+  return AMDR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int amdr_maxsim_create(const float* D_host, const int64_t* doc_ptr, int64_t n_docs, int32_t dim, int32_t device,
+                       amdr_maxsim_t** out) {
+  AMDR_REQUIRE(out != nullptr, "maxsim_create: out is null");
+  *out = nullptr;
+  AMDR_REQUIRE(dim == AMDR_MAXSIM_DIM, "maxsim_create: dim=%d, kernel is built for %d", dim, AMDR_MAXSIM_DIM);
+  AMDR_REQUIRE(doc_ptr && n_docs >= 1 && n_docs < (1ll << 32), "maxsim_create: bad doc_ptr / n_docs");
+  AMDR_REQUIRE(doc_ptr[0] == 0, "maxsim_create: doc_ptr[0] != 0");
+  for (int64_t i = 0; i < n_docs; ++i)
+    AMDR_REQUIRE(doc_ptr[i + 1] > doc_ptr[i], "maxsim_create: document %lld has no tokens", (long long)i);
+  const int64_t nt = doc_ptr[n_docs];
+  AMDR_REQUIRE(D_host != nullptr, "maxsim_create: D is null");
+  int rc = check_device(device);
+  if (rc) return rc;
+  amdr_maxsim* h = new (std::nothrow) amdr_maxsim();
+  if (!h) return fail(AMDR_ENOMEM, "maxsim_create: host alloc");
+  h->device = device;
+  h->n_docs = n_docs;
+  h->n_tokens = nt;
+  hipError_t e = hipMalloc((void**)&h->D, (size_t)nt * dim * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpy(h->D, D_host, (size_t)nt * dim * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->doc_ptr, (size_t)(n_docs + 1) * sizeof(long long));
+  if (e == hipSuccess)
+    e = hipMemcpy(h->doc_ptr, doc_ptr, (size_t)(n_docs + 1) * sizeof(long long), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    amdr_maxsim_destroy(h);
+    return fail(e == hipErrorOutOfMemory ? AMDR_ENOMEM : AMDR_EHIP, "maxsim_create: %s", hipGetErrorString(e));
+  }
+  *out = h;
+  return AMDR_OK;
+}
+
+int amdr_maxsim_ndocs(const amdr_maxsim_t* h, int64_t* n) {
+  AMDR_REQUIRE(h && n, "maxsim_ndocs: null");
+  *n = h->n_docs;
+  return AMDR_OK;
+}
+
+int amdr_maxsim_reserve(amdr_maxsim_t* h, int32_t nq_max, int32_t k_max) {
+  AMDR_REQUIRE(h != nullptr, "maxsim_reserve: null handle");
+  AMDR_REQUIRE(nq_max >= 1 && k_max >= 1 && k_max <= AMDR_MAX_K, "maxsim_reserve: bad sizes");
+  std::lock_guard<std::mutex> g(h->mu);
+  AMDR_HIP(hipSetDevice(h->device));
+  int rc = h->full.ensure((size_t)nq_max * h->n_docs * sizeof(float));
+  if (!rc) rc = h->qbuf.ensure((size_t)nq_max * AMDR_MAXSIM_QLEN * kDim * sizeof(float));
+  if (!rc) rc = h->sbuf.ensure((size_t)nq_max * k_max * sizeof(float));
+  if (!rc) rc = h->ibuf.ensure((size_t)nq_max * k_max * sizeof(int64_t));
+  return rc;
+}
+
+int amdr_maxsim_search_device(amdr_maxsim_t* h, const float* Q_dev, int32_t nq, int32_t q_len, int32_t k,
+                              float* scores_dev, int64_t* ids_dev, void* stream) {
+  int rc = ms_check(h, Q_dev, nq, q_len, k);
+  if (rc) return rc;
+  AMDR_REQUIRE(nq == 0 || (scores_dev && ids_dev), "maxsim: null output");
+  if (nq == 0) return AMDR_OK;
+  std::lock_guard<std::mutex> g(h->mu);
+  AMDR_HIP(hipSetDevice(h->device));
+  if ((rc = h->full.ensure((size_t)nq * h->n_docs * sizeof(float)))) return rc;
+  return ms_run(h, Q_dev, nq, q_len, k, h->full.as<float>(), scores_dev, ids_dev, (hipStream_t)stream);
+}
+
+int amdr_maxsim_search(amdr_maxsim_t* h, const float* Q_host, int32_t nq, int32_t q_len, int32_t k,
+                       float* scores_host, int64_t* ids_host) {
+  int rc = ms_check(h, Q_host, nq, q_len, k);
+  if (rc) return rc;
+  AMDR_REQUIRE(nq == 0 || (scores_host && ids_host), "maxsim: null output");
+  if (nq == 0) return AMDR_OK;
+  std::lock_guard<std::mutex> g(h->mu);
+  AMDR_HIP(hipSetDevice(h->device));
+  size_t qbytes = (size_t)nq * q_len * kDim * sizeof(float);
+  if ((rc = h->qbuf.ensure(qbytes))) return rc;
+  if ((rc = h->full.ensure((size_t)nq * h->n_docs * sizeof(float)))) return rc;
+  if ((rc = h->sbuf.ensure((size_t)nq * k * sizeof(float)))) return rc;
+  if ((rc = h->ibuf.ensure((size_t)nq * k * sizeof(int64_t)))) return rc;
+  AMDR_HIP(hipMemcpyAsync(h->qbuf.p, Q_host, qbytes, hipMemcpyHostToDevice, h->stream));
+  rc = ms_run(h, h->qbuf.as<float>(), nq, q_len, k, h->full.as<float>(), h->sbuf.as<float>(), h->ibuf.as<int64_t>(),
+              h->stream);
+  if (rc) return rc;
+  AMDR_HIP(hipMemcpyAsync(scores_host, h->sbuf.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  AMDR_HIP(hipMemcpyAsync(ids_host, h->ibuf.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+  AMDR_HIP(hipStreamSynchronize(h->stream));
+  return AMDR_OK;
+}
+
+int amdr_maxsim_scores(amdr_maxsim_t* h, const float* Q_host, int32_t nq, int32_t q_len, float* scores_host) {
+  int rc = ms_check(h, Q_host, nq, q_len, 1);
+  if (rc) return rc;
+  AMDR_REQUIRE(nq == 0 || scores_host, "maxsim_scores: null output");
+  if (nq == 0) return AMDR_OK;
+  std::lock_guard<std::mutex> g(h->mu);
+  AMDR_HIP(hipSetDevice(h->device));
+  size_t qbytes = (size_t)nq * q_len * kDim * sizeof(float);
+  if ((rc = h->qbuf.ensure(qbytes))) return rc;
+  if ((rc = h->full.ensure((size_t)nq * h->n_docs * sizeof(float)))) return rc;
+  AMDR_HIP(hipMemcpyAsync(h->qbuf.p, Q_host, qbytes, hipMemcpyHostToDevice, h->stream));
+  rc = ms_run(h, h->qbuf.as<float>(), nq, q_len, 1, h->full.as<float>(), nullptr, nullptr, h->stream);
+  if (rc) return rc;
+  AMDR_HIP(hipMemcpyAsync(scores_host, h->full.p, (size_t)nq * h->n_docs * sizeof(float), hipMemcpyDeviceToHost,
+                          h->stream));
+  AMDR_HIP(hipStreamSynchronize(h->stream));
+  return AMDR_OK;
+}
+
+int amdr_maxsim_destroy(amdr_maxsim_t* h) {
+  if (!h) return AMDR_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) {
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipStreamDestroy(h->stream);
+  }
+  if (h->D) (void)hipFree(h->D);
+  if (h->doc_ptr) (void)hipFree(h->doc_ptr);
+  h->full.release();
+  h->qbuf.release();
+  h->sbuf.release();
+  h->ibuf.release();
+  delete h;
+  return AMDR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,352 @@
+"""Parity of the HIP kernels (through the C ABI) against the CPU oracle.
+
+Bar (BASELINE.json north_star): bit-exact doc-id ranks and fp64 scores for
+BM25 and fusion; cosine / MaxSim scores within 1e-4 (fp32)."""
+import copy
+import math
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from helpers import assert_hits_equal_mod_ties
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from legal_rag_amd import _native
+    _native.load()
+    assert _native.device_count() >= 1, "no GPU visible"
+    assert _native.device_name(0).startswith("gfx950"), _native.device_name(0)
+    return _native
+
+
+def unit_rows(rng, n, d):
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    return X
+
+
+def check_dense(nat, X, Q, k):
+    from oracle import dense as OD
+    idx = nat.DenseIndex(X)
+    s, i = idx.search(Q, k)
+    ref = OD.flatip_scores(X, Q).astype(np.float64)
+    n = X.shape[0]
+    kk = min(k, n)
+    es, ei = OD.flatip_topk(X, Q, k)
+    for b in range(Q.shape[0]):
+        got_ids = i[b, :kk]
+        assert len(set(got_ids.tolist())) == kk and got_ids.min() >= 0 and got_ids.max() < n
+        # scores reported == exact score of the id reported, within 1e-4
+        assert np.max(np.abs(s[b, :kk] - ref[b, got_ids])) <= TOL
+        # sorted descending (by the kernel's own scores)
+        assert np.all(np.diff(s[b, :kk]) <= 0)
+        # same set as the oracle, except around near-ties at the k-th score
+        kth = es[b, kk - 1]
+        assert np.all(ref[b, got_ids] >= kth - TOL)
+        clear = ref[b, ei[b, :kk]] > kth + TOL  # oracle hits clearly above the cut must be present
+        assert set(ei[b, :kk][clear].tolist()) <= set(got_ids.tolist())
+        # rank agreement wherever neighbouring oracle scores are separated by > tol
+        gaps_ok = np.abs(np.diff(es[b, :kk])) > TOL
+        same = got_ids == ei[b, :kk]
+        sep = np.concatenate([[True], gaps_ok]) & np.concatenate([gaps_ok, [True]])
+        assert np.all(same[sep]), (b, got_ids, ei[b, :kk])
+        if k > n:
+            assert np.all(i[b, n:] == -1)
+            assert np.all(s[b, n:] == -np.finfo(np.float32).max)
+    idx.close()
+    return s, i
+
+
+@pytest.mark.parametrize("n,d,nq,k", [
+    (4096, 768, 16, 10),     # SURVEY §8c golden shape (3)
+    (591, 768, 5, 10),       # UCC-en sized
+    (591, 384, 3, 80),       # bge-small, eval depth
+    (1260, 1024, 9, 30),     # zh sized, bge-m3 dim
+    (7, 768, 2, 10),         # k > n: -1 padding
+    (1, 768, 1, 1),
+    (100000, 768, 8, 10),    # multi-block slabs, 8 queries per pass
+    (50000, 256, 33, 128),   # ragged query groups, deep k
+    (3000, 64, 4, 256),      # max k
+])
+def test_dense_topk_matches_oracle(nat, n, d, nq, k):
+    rng = np.random.default_rng(n * 31 + d + nq)
+    X = unit_rows(rng, n, d)
+    Q = unit_rows(rng, nq, d)
+    check_dense(nat, X, Q, k)
+
+
+def test_dense_golden_fixture(nat):
+    """Seeded fixture of SURVEY.md §8c(3): X[4096,768], Q[16,768], rng(0)."""
+    g = np.load(str(__import__("conftest").GOLDEN / "dense_flatip_golden.npz"))
+    rng = np.random.default_rng(0)
+    X = unit_rows(rng, 4096, 768)
+    Q = unit_rows(rng, 16, 768)
+    s, i = check_dense(nat, X, Q, 10)
+    assert np.array_equal(i, g["ids"])
+    assert np.max(np.abs(s - g["scores"])) <= TOL
+
+
+def test_dense_ties_lower_id_first(nat):
+    rng = np.random.default_rng(3)
+    base = unit_rows(rng, 50, 128)
+    X = np.concatenate([base, base, base], axis=0)  # every row appears 3x -> exact ties
+    Q = unit_rows(rng, 4, 128)
+    idx = nat.DenseIndex(X)
+    s, i = idx.search(Q, 9)
+    for b in range(4):
+        # hits come in triples of equal score with ascending ids r, r+50, r+100
+        for t in range(3):
+            tri = i[b, 3 * t:3 * t + 3]
+            assert tri[1] == tri[0] + 50 and tri[2] == tri[0] + 100
+            assert s[b, 3 * t] == s[b, 3 * t + 1] == s[b, 3 * t + 2]
+
+
+def test_dense_adversarial_ascending_scores(nat):
+    """Rows ordered so every new row beats all previous ones (worst case for the
+    threshold/staging selector): result must still be exact."""
+    d = 64
+    n = 20000
+    q = np.zeros((1, d), dtype=np.float32)
+    q[0, 0] = 1.0
+    X = np.zeros((n, d), dtype=np.float32)
+    X[:, 0] = np.linspace(-1.0, 1.0, n, dtype=np.float32)
+    X[:, 1] = 0.5
+    idx = nat.DenseIndex(X)
+    s, i = idx.search(q, 100)
+    assert i[0].tolist() == list(range(n - 1, n - 101, -1))
+    idx.close()
+
+
+def test_dense_add_and_read_rows(nat):
+    rng = np.random.default_rng(11)
+    X = unit_rows(rng, 300, 768)
+    idx = nat.DenseIndex(X[:100])
+    idx.add(X[100:250])
+    idx.add(X[250:])
+    assert idx.ntotal == 300
+    assert np.array_equal(idx.read_rows(90, 30), X[90:120])
+    from oracle import dense as OD
+    s, i = idx.search(X[[5, 170, 299]], 3)
+    assert i[:, 0].tolist() == [5, 170, 299]
+    es, ei = OD.flatip_topk(X, X[[5, 170, 299]], 3)
+    assert np.array_equal(i, ei)
+
+
+def test_dense_errors(nat):
+    with pytest.raises(nat.NativeError):
+        nat.DenseIndex(np.zeros((4, 770), dtype=np.float32))  # dim not multiple of 4
+    idx = nat.DenseIndex(np.zeros((4, 768), dtype=np.float32))
+    with pytest.raises(nat.NativeError):
+        idx.search(np.zeros((1, 768), dtype=np.float32), 0)
+    with pytest.raises(nat.NativeError):
+        idx.search(np.zeros((1, 768), dtype=np.float32), 257)
+    with pytest.raises(ValueError):
+        idx.search(np.zeros((1, 384), dtype=np.float32), 5)
+
+
+# ---------------------------------------------------------------------------
+def toy_corpus(rng, n_docs, vocab, max_len):
+    words = [f"w{i}" for i in range(vocab)]
+    p = 1.0 / np.arange(1, vocab + 1)
+    p /= p.sum()
+    docs = []
+    for _ in range(n_docs):
+        ln = int(rng.integers(0, max_len + 1))
+        docs.append([words[j] for j in rng.choice(vocab, size=ln, p=p)])
+    if all(len(d) == 0 for d in docs):
+        docs[0] = ["w0"]
+    return docs, words
+
+
+def bm25_pair(nat, docs):
+    from oracle import bm25 as OB
+    ob = OB.BM25Okapi(docs)
+    csr = OB.to_csr(ob)
+    gi = nat.BM25Index(csr["term_ptr"], csr["post_doc"], csr["post_tf"], csr["idf"], csr["doc_len"],
+                       ob.avgdl, ob.k1, ob.b)
+    return ob, csr, gi
+
+
+@pytest.mark.parametrize("n_docs,vocab,max_len,k", [
+    (591, 3926, 400, 10), (591, 3926, 400, 80), (12, 30, 8, 10), (5000, 500, 60, 10), (9000, 2000, 40, 256),
+    (1, 5, 5, 3),
+])
+def test_bm25_bit_exact(nat, n_docs, vocab, max_len, k):
+    from oracle import bm25 as OB
+    rng = np.random.default_rng(n_docs + vocab + k)
+    docs, words = toy_corpus(rng, n_docs, vocab, max_len)
+    ob, csr, gi = bm25_pair(nat, docs)
+    queries = []
+    for qi in range(12):
+        ln = int(rng.integers(0, 14))
+        toks = [words[j] for j in rng.integers(0, min(vocab, 60), size=ln)]
+        if qi % 3 == 0 and toks:
+            toks += [toks[0], "UNKNOWN", toks[-1]]  # duplicates + out-of-vocabulary
+        queries.append(toks)
+    queries.append([])
+    tid = [[csr["vocab"].get(t, -1) for t in q] for q in queries]
+    full = gi.get_scores(tid)
+    s, i = gi.search(tid, k)
+    for qn, q in enumerate(queries):
+        ref = ob.get_scores(q)
+        assert np.array_equal(full[qn], ref), f"query {qn}: scores differ"  # bit-exact fp64
+        exp = OB.search(ob, q, k)
+        kk = min(k, n_docs)
+        assert i[qn, :kk].tolist() == [e[0] for e in exp]
+        assert s[qn, :kk].tolist() == [e[1] for e in exp]
+        assert np.all(i[qn, kk:] == -1)
+
+
+def test_bm25_toy_golden(nat):
+    g = load_golden("bm25_toy.json")
+    from oracle import bm25 as OB
+    docs = [OB.tokenize_en(t) for t in g["docs"]]
+    ob, csr, gi = bm25_pair(nat, docs)
+    assert [float(x) for x in csr["idf"]] == [g["idf"][w] for w in csr["vocab"]]
+    for case in g["queries"]:
+        tid = [[csr["vocab"].get(t, -1) for t in case["tokens"]]]
+        assert gi.get_scores(tid)[0].tolist() == case["scores"]
+        s, i = gi.search(tid, len(docs))
+        assert i[0].tolist() == case["order"]
+
+
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("n_docs,nq,q_len,k", [(591, 3, 32, 10), (40, 2, 32, 80), (200, 2, 17, 5), (3, 1, 32, 10)])
+def test_maxsim_matches_oracle(nat, n_docs, nq, q_len, k):
+    from oracle import maxsim as OM
+    rng = np.random.default_rng(n_docs + q_len)
+    lens = rng.integers(1, 221, size=n_docs)
+    lens[0] = 1
+    lens[-1] = 220
+    if n_docs > 5:
+        lens[1:5] = [31, 32, 33, 64]
+    doc_ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    D = unit_rows(rng, int(doc_ptr[-1]), 128)
+    Q = unit_rows(rng, nq * q_len, 128).reshape(nq, q_len, 128)
+    # make some similarities strongly negative so padding rows would win if unmasked
+    D[doc_ptr[0]] = -Q[0, 0]
+    idx = nat.MaxSimIndex(D, doc_ptr)
+    full = idx.scores(Q)
+    ref = OM.maxsim_scores(Q, D, doc_ptr)
+    assert np.max(np.abs(full - ref)) <= TOL
+    s, i = idx.search(Q, k)
+    es, ei = OM.maxsim_topk(Q, D, doc_ptr, k)
+    kk = min(k, n_docs)
+    for b in range(nq):
+        got = i[b, :kk]
+        assert len(set(got.tolist())) == kk
+        assert np.max(np.abs(s[b, :kk] - ref[b, got])) <= TOL
+        gaps_ok = np.abs(np.diff(es[b, :kk])) > 2 * TOL
+        sep = np.concatenate([[True], gaps_ok]) & np.concatenate([gaps_ok, [True]])
+        assert np.all((got == ei[b, :kk])[sep])
+        assert np.all(i[b, kk:] == -1)
+
+
+def test_maxsim_rejects_empty_doc(nat):
+    with pytest.raises(nat.NativeError):
+        nat.MaxSimIndex(np.zeros((4, 128), np.float32), np.array([0, 2, 2, 4]))
+    with pytest.raises(nat.NativeError):
+        nat.MaxSimIndex(np.zeros((4, 64), np.float32), np.array([0, 4]))
+
+
+# ---------------------------------------------------------------------------
+FUSE = load_golden("fusion_golden.json")["cases"]
+SEARCH = load_golden("search_golden.json")["cases"]
+
+
+def _arr(case, ch, dtype):
+    rows = sorted(case[ch], key=lambda p: -p[1])
+    ids = np.array([[p[0] for p in rows]], dtype=np.int64).reshape(1, -1)
+    sc = np.array([[p[1] for p in rows]], dtype=dtype).reshape(1, -1)
+    return ids, sc
+
+
+def _params(nat, kn, min_final=-math.inf):
+    return nat.make_fuse_params(
+        method=kn.get("fusion_method", "rrf_norm_blend"), rrf_k=kn.get("rrf_k", 60), alpha=kn.get("rrf_alpha", 0.5),
+        w_dense=kn.get("dense_weight", 0.6), w_bm25=kn.get("bm25_weight", 0.4),
+        w_colbert=kn.get("colbert_weight", 0.35), min_final_score=min_final)
+
+
+def _hits_from_native(nat, ids, vals, mask, count, kn, *, rer=None, beta=None):
+    names = ("dense", "bm25", "colbert")
+    out = []
+    for r in range(int(count)):
+        v = vals[r]
+        contrib = {n: float(v[6 + c]) for c, n in enumerate(names)}
+        members = [n for c, n in enumerate(names) if mask[r] & (1 << c)]
+        members.sort(key=lambda c: (contrib[c], c), reverse=True)
+        sb = {
+            "fusion_method": str(kn.get("fusion_method", "rrf_norm_blend")).lower(), "rrf_k": int(kn.get("rrf_k", 60)),
+            "alpha": float(kn.get("rrf_alpha", 0.5)),
+            "channel_weights": {"dense": float(kn.get("dense_weight", 0.6)), "bm25": float(kn.get("bm25_weight", 0.4)),
+                                "colbert": float(kn.get("colbert_weight", 0.35))},
+            "channel": members, "channel_contrib": contrib, "rrf_norm": float(v[1]), "weighted_sum": float(v[2]),
+            "dense_norm": float(v[3]), "bm25_norm": float(v[4]), "colbert_norm": float(v[5]),
+        }
+        src = "retriever"
+        if rer is not None and not math.isnan(rer[r, 0]):
+            sb.update({"rerank_raw": float(rer[r, 0]), "rerank_norm": float(rer[r, 1]), "rerank_beta": beta})
+            src = "rerank"
+        out.append({"id": f"src.txt::{int(ids[r])}", "score": float(v[0]), "rank": r + 1, "source": src,
+                    "breakdown": sb})
+    return out
+
+
+@pytest.mark.parametrize("case", FUSE, ids=[c["name"] for c in FUSE])
+def test_fuse_kernel_bit_exact_vs_reference_vectors(nat, case):
+    kn = case["knobs"]
+    d = _arr(case, "dense", np.float32)
+    b = _arr(case, "bm25", np.float64)
+    c = _arr(case, "colbert", np.float32)
+    ids, vals, mask, count = nat.fuse(_params(nat, kn), 1, d, b, c)
+    got = _hits_from_native(nat, ids[0], vals[0], mask[0], count[0], kn)
+    assert_hits_equal_mod_ties(got, case["expected"])
+
+
+@pytest.mark.parametrize("case", SEARCH, ids=[c["name"] for c in SEARCH])
+def test_fuse_filter_rerank_pipeline_vs_reference_vectors(nat, case):
+    """fuse -> min_final filter -> rerank blend -> top_k through the C ABI,
+    against vectors produced by the reference's HybridRetriever.search()."""
+    from oracle import fusion as F
+    kn = {k: v for k, v in case["knobs"].items() if k != "enable_graph"}
+    full = dict(F.DEFAULTS)
+    full.update(kn)
+    top_k = case["top_k"]
+    eff = F.eff_top_k(top_k, full["top_k"])
+    cut = copy.deepcopy(case)
+    for ch in ("dense", "bm25", "colbert"):
+        cut[ch] = sorted(case[ch], key=lambda p: -p[1])[:eff]
+    d = _arr(cut, "dense", np.float32)
+    b = _arr(cut, "bm25", np.float64)
+    c = _arr(cut, "colbert", np.float32)
+    ids, vals, mask, count = nat.fuse(_params(nat, full, full["min_final_score"]), 1, d, b, c)
+    rer = None
+    if full["enable_rerank"] and count[0] > 0:
+        n = min(int(full["rerank_top_n"]), int(count[0]))
+        raw = np.array([[case["ce_raw_by_id"][f"src.txt::{int(i)}"] for i in ids[0, :n]]], dtype=np.float64)
+        rer = nat.rerank_blend(count, ids, vals, mask, raw, float(full["rerank_beta"]))[0]
+    got = _hits_from_native(nat, ids[0], vals[0], mask[0], count[0], full, rer=rer, beta=float(full["rerank_beta"]))
+    assert_hits_equal_mod_ties(got[:top_k], case["expected"])
+
+
+def test_fuse_batched_equals_single(nat):
+    rng = np.random.default_rng(9)
+    nq, k = 37, 10
+    di = np.stack([rng.choice(200, size=k, replace=False) for _ in range(nq)]).astype(np.int64)
+    bi = np.stack([rng.choice(200, size=k, replace=False) for _ in range(nq)]).astype(np.int64)
+    ds = -np.sort(-rng.uniform(0, 1, size=(nq, k)).astype(np.float32), axis=1)
+    bs = -np.sort(-rng.uniform(0, 30, size=(nq, k)), axis=1)
+    bi[3, 6:] = -1  # ragged channel
+    p = nat.make_fuse_params(min_final_score=0.2)
+    I, V, M, Cn = nat.fuse(p, nq, (di, ds), (bi, bs), None)
+    for q in range(nq):
+        i1, v1, m1, c1 = nat.fuse(p, 1, (di[q:q + 1], ds[q:q + 1]), (bi[q:q + 1], bs[q:q + 1]), None)
+        assert np.array_equal(I[q], i1[0]) and np.array_equal(V[q], v1[0]) and np.array_equal(M[q], m1[0])
+        assert Cn[q] == c1[0]
