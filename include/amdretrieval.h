@@ -68,6 +68,12 @@ int amdr_dense_search_device(amdr_dense_t* h, const float* Q_dev, int32_t nq, in
 /* copy rows [row0, row0+nrows) back to the host (used by parity tests to run
  * the oracle on exactly the matrix that is resident in HBM) */
 int amdr_dense_read_rows(const amdr_dense_t* h, int64_t row0, int64_t nrows, float* out_host);
+/* HIP-event bracket around the scan kernel alone (not the merge), recorded on
+ * the stream each search is launched on; used by bench.py for the roofline.
+ * begin() arms up to max_launches event pairs, end() returns the summed scan
+ * time and the number of launches measured since begin(). */
+int amdr_dense_profile_begin(amdr_dense_t* h, int32_t max_launches);
+int amdr_dense_profile_end(amdr_dense_t* h, double* total_ms, int32_t* launches);
 int amdr_dense_destroy(amdr_dense_t* h);
 
 /* ---- BM25 channel: Okapi scoring over term-major CSR postings ----------
@@ -148,10 +154,12 @@ typedef struct amdr_fuse_params {
  * out_ids [nq,max_out], out_vals [nq,max_out,AMDR_FUSE_NVALS], out_mask
  * [nq,max_out] (bit0 dense, bit1 bm25, bit2 colbert membership), out_count
  * [nq] = hits surviving the min_final_score filter. */
+/* host-pointer form: every channel's scores as double (callers of _fuse may
+ * hand in arbitrary Python floats; fp32 channel scores widen exactly) */
 int amdr_fuse(const amdr_fuse_params_t* p, int32_t nq,
-              const int64_t* dense_ids, const float* dense_scores, int32_t kd,
+              const int64_t* dense_ids, const double* dense_scores, int32_t kd,
               const int64_t* bm25_ids, const double* bm25_scores, int32_t kb,
-              const int64_t* colbert_ids, const float* colbert_scores, int32_t kc,
+              const int64_t* colbert_ids, const double* colbert_scores, int32_t kc,
               int64_t* out_ids, double* out_vals, int32_t* out_mask, int32_t* out_count);
 int amdr_fuse_device(const amdr_fuse_params_t* p, int32_t nq,
                      const int64_t* dense_ids, const float* dense_scores, int32_t kd, const int64_t* dense_row2uid,

@@ -30,7 +30,7 @@ EXPORTS = (
     "amdr_last_error", "amdr_version", "amdr_device_count", "amdr_device_name",
     "amdr_dense_create", "amdr_dense_create_from_device", "amdr_dense_add", "amdr_dense_ntotal", "amdr_dense_dim",
     "amdr_dense_reserve", "amdr_dense_search", "amdr_dense_search_device", "amdr_dense_read_rows",
-    "amdr_dense_destroy",
+    "amdr_dense_profile_begin", "amdr_dense_profile_end", "amdr_dense_destroy",
     "amdr_bm25_create", "amdr_bm25_ndocs", "amdr_bm25_reserve", "amdr_bm25_search", "amdr_bm25_search_device",
     "amdr_bm25_scores", "amdr_bm25_destroy",
     "amdr_maxsim_create", "amdr_maxsim_ndocs", "amdr_maxsim_reserve", "amdr_maxsim_search",
@@ -64,6 +64,15 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own libamdhip64.so (SONAME libamdhip64.so.7).  If torch is
+    # going to be used in this process it must be loaded FIRST so that this library's
+    # NEEDED libamdhip64.so.7 resolves to the runtime torch already mapped: one HIP runtime
+    # per process, and torch device pointers / stream handles are then valid here.
+    if os.environ.get("AMDR_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:  # noqa: BLE001 - torch is optional for the numpy-only API
+            pass
     p = lib_path()
     if not p.exists():
         raise NativeError(
@@ -176,6 +185,14 @@ class DenseIndex:
         _check(load().amdr_dense_read_rows(self._h, C.c_int64(row0), C.c_int64(nrows), _p(out, C.c_float)),
                "amdr_dense_read_rows")
         return out
+
+    def profile_begin(self, max_launches: int) -> None:
+        _check(load().amdr_dense_profile_begin(self._h, C.c_int32(max_launches)), "amdr_dense_profile_begin")
+
+    def profile_end(self) -> Tuple[float, int]:
+        ms, n = C.c_double(0), C.c_int32(0)
+        _check(load().amdr_dense_profile_end(self._h, C.byref(ms), C.byref(n)), "amdr_dense_profile_end")
+        return float(ms.value), int(n.value)
 
     def close(self) -> None:
         if getattr(self, "_h", None) and self._h.value:
@@ -345,9 +362,9 @@ def _chan(ids, scores, sdtype, nq):
 def fuse(params: FuseParams, nq: int, dense=None, bm25=None, colbert=None):
     """Host-pointer fusion. Each channel is (ids i64[nq,k], scores[nq,k]) or None.
     Returns (ids [nq,max_out], vals [nq,max_out,9], mask [nq,max_out], count [nq])."""
-    di, ds, kd = _chan(*(dense or (None, None)), np.float32, nq)
+    di, ds, kd = _chan(*(dense or (None, None)), np.float64, nq)
     bi, bs, kb = _chan(*(bm25 or (None, None)), np.float64, nq)
-    ci, cs, kc = _chan(*(colbert or (None, None)), np.float32, nq)
+    ci, cs, kc = _chan(*(colbert or (None, None)), np.float64, nq)
     mo = kd + kb + kc
     out_ids = np.full((nq, max(mo, 1)), -1, dtype=np.int64)
     out_vals = np.zeros((nq, max(mo, 1), FUSE_NVALS), dtype=np.float64)
@@ -355,9 +372,9 @@ def fuse(params: FuseParams, nq: int, dense=None, bm25=None, colbert=None):
     out_count = np.zeros((nq,), dtype=np.int32)
     if mo == 0 or nq == 0:
         return out_ids[:, :0], out_vals[:, :0], out_mask[:, :0], out_count
-    _check(load().amdr_fuse(C.byref(params), C.c_int32(nq), _p(di, C.c_int64), _p(ds, C.c_float), C.c_int32(kd),
+    _check(load().amdr_fuse(C.byref(params), C.c_int32(nq), _p(di, C.c_int64), _p(ds, C.c_double), C.c_int32(kd),
                             _p(bi, C.c_int64), _p(bs, C.c_double), C.c_int32(kb), _p(ci, C.c_int64),
-                            _p(cs, C.c_float), C.c_int32(kc), _p(out_ids, C.c_int64), _p(out_vals, C.c_double),
+                            _p(cs, C.c_double), C.c_int32(kc), _p(out_ids, C.c_int64), _p(out_vals, C.c_double),
                             _p(out_mask, C.c_int32), _p(out_count, C.c_int32)), "amdr_fuse")
     return out_ids, out_vals, out_mask, out_count
 

@@ -15,6 +15,7 @@
 #include <cfloat>
 #include <mutex>
 #include <new>
+#include <vector>
 
 namespace amdr {
 
@@ -227,6 +228,10 @@ struct amdr_dense {
   hipStream_t stream = nullptr;
   std::mutex mu;
   DevBuf part, qbuf, sbuf, ibuf;
+  // optional HIP-event ring bracketing the scan kernel alone (bench.py roofline)
+  std::vector<hipEvent_t> prof_ev;
+  int prof_used = 0;
+  bool prof_on = false;
 };
 
 namespace {
@@ -251,10 +256,15 @@ int make_plan(int64_t n, int d, int nq, int k, ScanPlan* p) {
   while (nqb > 1 && nqb / 2 >= nq) nqb >>= 1;
   p->nq_per_block = nqb;
   const int U = (nqb <= 2) ? 4 : 2;
-  long min_rows = (long)kWaves * U * 4;  // at least a few iterations per block
-  long max_blocks = 256L * 8;
-  long gx = (n + min_rows - 1) / min_rows;
-  if (gx > max_blocks) gx = max_blocks;
+  // Row slabs: enough blocks to fill 256 CUs several times over, but never thinner than a
+  // few iterations per wave — the per-block top-k finalisation is a fixed cost per slab,
+  // so when there are already many query groups (grid_y) the slabs get fatter instead.
+  p->grid_y = ceil_div(nq, nqb);
+  long min_rows = (long)kWaves * U * 4;
+  long want_blocks = 256L * 8;
+  long gx = (want_blocks + p->grid_y - 1) / p->grid_y;
+  long gx_max = (n + min_rows - 1) / min_rows;
+  if (gx > gx_max) gx = gx_max;
   if (gx < 1) gx = 1;
   p->rows_per_block = (n + gx - 1) / gx;
   // round the slab to a multiple of the block's row stride so waves stay aligned
@@ -294,6 +304,8 @@ int run_search(amdr_dense* h, const float* Q_dev, int nq, int k, float* scores_d
   int rc = h->part.ensure(p.part_bytes);
   if (rc) return rc;
   C32* part = h->part.as<C32>();
+  const bool prof = h->prof_on && (size_t)(h->prof_used + 2) <= h->prof_ev.size() && h->n > 0;
+  if (prof) AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
   if (h->n > 0) {
     switch (p.nq_per_block) {
       case 1: rc = launch_scan_ch<1>(p, h, Q_dev, nq, k, part, st); break;
@@ -303,6 +315,10 @@ int run_search(amdr_dense* h, const float* Q_dev, int nq, int k, float* scores_d
     }
     if (rc) return rc;
     AMDR_HIP(hipGetLastError());
+  }
+  if (prof) {
+    AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
+    h->prof_used += 2;
   }
   int nparts = h->n > 0 ? p.grid_x : 0;
   size_t lds = (size_t)kWaves * p.cap * sizeof(C32) + kWaves * sizeof(int);
@@ -463,9 +479,42 @@ int amdr_dense_read_rows(const amdr_dense_t* h, int64_t row0, int64_t nrows, flo
   return AMDR_OK;
 }
 
+int amdr_dense_profile_begin(amdr_dense_t* h, int32_t max_launches) {
+  AMDR_REQUIRE(h != nullptr && max_launches >= 1 && max_launches <= (1 << 16), "dense_profile_begin: bad arguments");
+  std::lock_guard<std::mutex> g(h->mu);
+  AMDR_HIP(hipSetDevice(h->device));
+  while (h->prof_ev.size() < (size_t)max_launches * 2) {
+    hipEvent_t e;
+    AMDR_HIP(hipEventCreate(&e));
+    h->prof_ev.push_back(e);
+  }
+  h->prof_used = 0;
+  h->prof_on = true;
+  return AMDR_OK;
+}
+
+int amdr_dense_profile_end(amdr_dense_t* h, double* total_ms, int32_t* launches) {
+  AMDR_REQUIRE(h && total_ms && launches, "dense_profile_end: null");
+  std::lock_guard<std::mutex> g(h->mu);
+  AMDR_HIP(hipSetDevice(h->device));
+  h->prof_on = false;
+  double tot = 0;
+  for (int i = 0; i + 1 < h->prof_used; i += 2) {
+    float ms = 0;
+    AMDR_HIP(hipEventSynchronize(h->prof_ev[i + 1]));
+    AMDR_HIP(hipEventElapsedTime(&ms, h->prof_ev[i], h->prof_ev[i + 1]));
+    tot += ms;
+  }
+  *total_ms = tot;
+  *launches = h->prof_used / 2;
+  h->prof_used = 0;
+  return AMDR_OK;
+}
+
 int amdr_dense_destroy(amdr_dense_t* h) {
   if (!h) return AMDR_OK;
   (void)hipSetDevice(h->device);
+  for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
   if (h->stream) {
     (void)hipStreamSynchronize(h->stream);
     (void)hipStreamDestroy(h->stream);

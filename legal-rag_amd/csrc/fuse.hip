@@ -397,9 +397,9 @@ int amdr_rerank_blend_device(int32_t nq, int32_t max_out, const int32_t* count, 
   return AMDR_OK;
 }
 
-int amdr_fuse(const amdr_fuse_params_t* p, int32_t nq, const int64_t* dense_ids, const float* dense_scores, int32_t kd,
+int amdr_fuse(const amdr_fuse_params_t* p, int32_t nq, const int64_t* dense_ids, const double* dense_scores, int32_t kd,
               const int64_t* bm25_ids, const double* bm25_scores, int32_t kb, const int64_t* colbert_ids,
-              const float* colbert_scores, int32_t kc, int64_t* out_ids, double* out_vals, int32_t* out_mask,
+              const double* colbert_scores, int32_t kc, int64_t* out_ids, double* out_vals, int32_t* out_mask,
               int32_t* out_count) {
   int rc = fuse_check(p, nq, kd, kb, kc);
   if (rc) return rc;
@@ -419,10 +419,15 @@ int amdr_fuse(const amdr_fuse_params_t* p, int32_t nq, const int64_t* dense_ids,
   if ((rc = to_dev(ov, (const double*)nullptr, (size_t)nq * mo * AMDR_FUSE_NVALS, st))) return rc;
   if ((rc = to_dev(om, (const int32_t*)nullptr, (size_t)nq * mo, st))) return rc;
   if ((rc = to_dev(oc, (const int32_t*)nullptr, (size_t)nq, st))) return rc;
-  rc = amdr_fuse_device(p, nq, (const int64_t*)di.p, (const float*)ds.p, kd, nullptr, (const int64_t*)bi.p,
-                        (const double*)bs.p, kb, nullptr, (const int64_t*)ci.p, (const float*)cs.p, kc, nullptr,
-                        (int64_t*)oi.p, (double*)ov.p, (int32_t*)om.p, (int32_t*)oc.p, dev, st);
-  if (rc) return rc;
+  AMDR_REQUIRE((kd == 0 || (dense_ids && dense_scores)) && (kb == 0 || (bm25_ids && bm25_scores)) &&
+                   (kc == 0 || (colbert_ids && colbert_scores)) && out_ids && out_vals && out_mask && out_count,
+               "fuse: null buffer");
+  ChanIn c0{(const long long*)di.p, ds.p, nullptr, kd, 1};
+  ChanIn c1{(const long long*)bi.p, bs.p, nullptr, kb, 1};
+  ChanIn c2{(const long long*)ci.p, cs.p, nullptr, kc, 1};
+  hipLaunchKernelGGL(fuse_kernel, dim3(nq), dim3(64), 0, st, *p, c0, c1, c2, mo, (long long*)oi.p, (double*)ov.p,
+                     (int*)om.p, (int*)oc.p);
+  AMDR_HIP(hipGetLastError());
   AMDR_HIP(hipMemcpyAsync(out_ids, oi.p, (size_t)nq * mo * sizeof(int64_t), hipMemcpyDeviceToHost, st));
   AMDR_HIP(hipMemcpyAsync(out_vals, ov.p, (size_t)nq * mo * AMDR_FUSE_NVALS * sizeof(double), hipMemcpyDeviceToHost, st));
   AMDR_HIP(hipMemcpyAsync(out_mask, om.p, (size_t)nq * mo * sizeof(int32_t), hipMemcpyDeviceToHost, st));

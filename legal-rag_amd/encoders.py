@@ -1,0 +1,194 @@
+"""Text encoders of the retrieval path (host + PyTorch-ROCm plumbing).
+
+The reference calls FlagEmbedding.FlagModel (vector_store.py:65-77,131-155),
+colbert-ai's checkpoint encoder and sentence_transformers.CrossEncoder
+(rerankers.py:93-116).  None of those wheels, and no model weights, exist in the
+build container, so:
+  * `TransformersBGE` runs the published BGE recipe on PyTorch-ROCm with plain
+    `transformers` (CLS pooling, L2 normalisation, fp16 on GPU, query
+    instruction prepended) when a LOCAL checkpoint directory is available;
+    encoder-output parity with FlagModel is unpinned (no weights to compare).
+  * `HashingEmbedder` / `HashingTokenEmbedder` / `HashingCrossScorer` are
+    deterministic stand-ins (seeded hashed-token random projections) used by
+    tests and bench.py so the ENGINE can be exercised end to end.  They are
+    only ever selected explicitly (`encoder_backend="hashing"`), never as a
+    silent fallback.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import re
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+QUERY_INSTRUCTION = "为这个法律问题生成表示以用于检索相关法律条文："  # vector_store.py:72 (used for zh AND en)
+
+_WORD_RE = re.compile(r"[A-Za-z0-9]+|[一-鿿]")
+
+
+def _tok(text: str) -> List[str]:
+    return _WORD_RE.findall(text.lower())
+
+
+def _seed(token: str, salt: str) -> int:
+    return int.from_bytes(hashlib.blake2b((salt + "\0" + token).encode("utf-8"), digest_size=8).digest(), "little")
+
+
+class _VecCache:
+    def __init__(self, dim: int, salt: str):
+        self.dim, self.salt, self.cache = dim, salt, {}
+
+    def vec(self, token: str) -> np.ndarray:
+        v = self.cache.get(token)
+        if v is None:
+            v = np.random.default_rng(_seed(token, self.salt)).standard_normal(self.dim).astype(np.float32)
+            self.cache[token] = v
+        return v
+
+
+class HashingEmbedder:
+    """Deterministic bag-of-hashed-tokens sentence embedding (stand-in for BGE)."""
+
+    def __init__(self, dim: int = 768, salt: str = "bge-standin"):
+        self.dim = dim
+        self._c = _VecCache(dim, salt)
+
+    @property
+    def hidden_size(self) -> int:
+        return self.dim
+
+    def _one(self, text: str) -> np.ndarray:
+        toks = _tok(text)
+        acc = np.zeros(self.dim, dtype=np.float64)
+        if not toks:
+            toks = ["<empty>"]
+        counts = {}
+        for t in toks:
+            counts[t] = counts.get(t, 0) + 1
+        for t, c in counts.items():
+            acc += (1.0 + np.log(c)) * self._c.vec(t)
+        n = np.linalg.norm(acc)
+        return (acc / (n if n > 0 else 1.0)).astype(np.float32)
+
+    def encode(self, texts: Sequence[str], batch_size: int = 64, max_length: int = 512) -> np.ndarray:
+        if isinstance(texts, str):
+            return self._one(texts)
+        if len(texts) == 0:
+            return np.zeros((0, self.dim), dtype=np.float32)
+        return np.stack([self._one(t) for t in texts])
+
+    def encode_queries(self, texts: Sequence[str], batch_size: int = 64, max_length: int = 512) -> np.ndarray:
+        # the stand-in ignores the instruction prefix (it would add the same vector to every query)
+        return self.encode(texts, batch_size=batch_size, max_length=max_length)
+
+
+class HashingTokenEmbedder:
+    """Stand-in for the ColBERT checkpoint: one seeded unit 128-d vector per token,
+    mixed with a document-position-free context vector.  Queries are padded to
+    32 tokens with a [MASK] vector like ColBERT's query augmentation."""
+
+    def __init__(self, dim: int = 128, doc_maxlen: int = 220, query_maxlen: int = 32, salt: str = "colbert-standin"):
+        self.dim, self.doc_maxlen, self.query_maxlen = dim, doc_maxlen, query_maxlen
+        self._c = _VecCache(dim, salt)
+
+    def _unit(self, toks: List[str]) -> np.ndarray:
+        M = np.stack([self._c.vec(t) for t in toks]).astype(np.float32)
+        M /= np.linalg.norm(M, axis=1, keepdims=True)
+        return M
+
+    def encode_doc(self, text: str) -> np.ndarray:
+        toks = (["[D]"] + _tok(text))[: self.doc_maxlen]
+        return self._unit(toks)
+
+    def encode_query(self, text: str) -> np.ndarray:
+        toks = (["[Q]"] + _tok(text))[: self.query_maxlen]
+        toks = toks + ["[MASK]"] * (self.query_maxlen - len(toks))
+        return self._unit(toks)
+
+
+class HashingCrossScorer:
+    """Stand-in for the cross-encoder: sigmoid of a token-overlap statistic."""
+
+    def score_batch(self, query: str, docs: List[str]) -> List[float]:
+        q = set(_tok(query))
+        out = []
+        for d in docs:
+            t = _tok(d)
+            ov = sum(1 for x in t if x in q) / (1.0 + len(t)) if t else 0.0
+            h = (_seed(d, query) % 1000) / 1e6  # tiny deterministic jitter: no exact ties
+            out.append(float(1.0 / (1.0 + np.exp(-(8.0 * ov - 1.0))) + h))
+        return out
+
+    def score(self, query: str, doc: str) -> float:
+        return self.score_batch(query, [doc])[0]
+
+
+class TransformersBGE:
+    """BGE sentence encoder on PyTorch-ROCm (plain transformers; FlagModel recipe)."""
+
+    def __init__(self, model_path: str, device: Optional[str] = None,
+                 query_instruction: str = QUERY_INSTRUCTION):
+        import torch
+        from transformers import AutoModel, AutoTokenizer
+
+        self.torch = torch
+        self.device = torch.device(device or ("cuda" if torch.cuda.is_available() else "cpu"))
+        self.tokenizer = AutoTokenizer.from_pretrained(model_path, local_files_only=True)
+        self.model = AutoModel.from_pretrained(model_path, local_files_only=True).to(self.device).eval()
+        self.use_fp16 = self.device.type == "cuda"
+        if self.use_fp16:
+            self.model = self.model.half()
+        self.query_instruction = query_instruction
+
+    @property
+    def hidden_size(self) -> int:
+        return int(self.model.config.hidden_size)
+
+    def encode(self, texts, batch_size: int = 64, max_length: int = 512) -> np.ndarray:
+        torch = self.torch
+        single = isinstance(texts, str)
+        if single:
+            texts = [texts]
+        if len(texts) == 0:
+            return np.zeros((0, self.hidden_size), dtype=np.float32)
+        order = np.argsort([-len(t) for t in texts])  # length-sorted batches, like FlagModel
+        out = np.zeros((len(texts), self.hidden_size), dtype=np.float32)
+        with torch.inference_mode():
+            for s in range(0, len(texts), batch_size):
+                idx = order[s:s + batch_size]
+                enc = self.tokenizer([texts[i] for i in idx], padding=True, truncation=True, max_length=max_length,
+                                     return_tensors="pt").to(self.device)
+                h = self.model(**enc).last_hidden_state[:, 0]
+                h = torch.nn.functional.normalize(h.float(), dim=-1)
+                out[idx] = h.cpu().numpy()
+        return out[0] if single else out
+
+    def encode_queries(self, texts, batch_size: int = 64, max_length: int = 512) -> np.ndarray:
+        if isinstance(texts, str):
+            return self.encode(self.query_instruction + texts, batch_size, max_length)
+        return self.encode([self.query_instruction + t for t in texts], batch_size, max_length)
+
+
+_EMBEDDER_CACHE = {}
+
+
+def get_embedder(model_name: str, backend: str = "auto", dim: int = 768):
+    """Resolve the sentence encoder.  'hashing' -> stand-in; 'transformers' ->
+    local checkpoint required; 'auto' -> local checkpoint if `model_name` is a
+    directory, else an error naming what is missing (no silent stand-in)."""
+    key = (model_name, backend, dim)
+    if key in _EMBEDDER_CACHE:
+        return _EMBEDDER_CACHE[key]
+    if backend == "hashing":
+        m = HashingEmbedder(dim=dim)
+    elif os.path.isdir(model_name):
+        m = TransformersBGE(model_name)
+    else:
+        raise RuntimeError(
+            f"embedding model '{model_name}' is not a local checkpoint directory and this build has no network; "
+            f"point cfg.retrieval.embedding_model at a downloaded BGE checkpoint or set "
+            f"cfg.retrieval.encoder_backend='hashing' to use the deterministic stand-in.")
+    _EMBEDDER_CACHE[key] = m
+    return m

@@ -1,0 +1,71 @@
+"""Sparse channel (legalrag/retrieval/bm25_retriever.py:19-76).
+
+`load()` unpickles {"bm25", "chunks"} (RuntimeError when the file is missing or
+has no "bm25", mtime-guarded reload); `search()` tokenises the query with
+jieba.cut WITHOUT lower-casing (:73), scores every document with Okapi BM25 and
+returns the first top_k of a stable descending sort — zero-score documents
+included, ties in ascending document order (:74-76).  Scoring and ranking run in
+the HIP kernel (csrc/bm25.hip), bit-identical to rank_bm25's float64 numpy
+expression."""
+from __future__ import annotations
+
+import threading
+from pathlib import Path
+from typing import List, Tuple
+
+from .. import artifacts, text
+from ..bm25_model import BM25Okapi
+from ..schemas import LawChunk
+
+
+class BM25Retriever:
+    def __init__(self, cfg):
+        self.cfg = cfg
+        rcfg = cfg.retrieval
+        self.bm25_path = Path(rcfg.bm25_index_file)
+        self.device_index = int(getattr(rcfg, "device", 0))
+        self._loaded = False
+        self._bm25_mtime: float | None = None
+        self.bm25: BM25Okapi | None = None
+        self.chunks: List[LawChunk] = []
+        self._lock = threading.Lock()
+
+    def load(self) -> None:
+        if not self.bm25_path.exists():
+            raise RuntimeError(
+                f"[BM25] index not found: {self.bm25_path}. "
+                f"Run: python build_index.py (or python build_index.py --only-bm25)")
+        current_mtime = self.bm25_path.stat().st_mtime
+        if self._loaded and self._bm25_mtime == current_mtime:
+            return
+        with self._lock:
+            if self._loaded and self._bm25_mtime == current_mtime:
+                return
+            bm25, chunks = artifacts.read_bm25_pickle(self.bm25_path)
+            bm25.gpu(self.device_index)  # upload CSR postings now, not on the first query
+            self.bm25 = bm25
+            self.chunks = chunks
+            self._loaded = True
+            self._bm25_mtime = current_mtime
+
+    def search(self, query: str, top_k: int) -> List[Tuple[LawChunk, float]]:
+        self.load()
+        assert self.bm25 is not None
+        tokens = text.jieba_cut(query)
+        k = int(top_k)
+        if k <= 0:
+            return []
+        out: List[Tuple[LawChunk, float]] = []
+        n = len(self.chunks)
+        # the kernel ranks at most MAX_K per call; deeper requests take the dense score vector
+        from .._native import MAX_K
+        if k <= MAX_K:
+            scores, ids = self.bm25.top_k(tokens, min(k, MAX_K), device=self.device_index)
+            for s, i in zip(scores.tolist(), ids.tolist()):
+                if i < 0:
+                    break
+                out.append((self.chunks[i], float(s)))
+            return out
+        scores = self.bm25.get_scores(tokens, device=self.device_index)
+        idxs = sorted(range(n), key=lambda i: scores[i], reverse=True)[:k]
+        return [(self.chunks[i], float(scores[i])) for i in idxs]

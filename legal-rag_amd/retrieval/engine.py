@@ -1,0 +1,147 @@
+"""Batched, device-resident hybrid pipeline (the throughput path).
+
+The reference answers one query per `HybridRetriever.search` call
+(hybrid_retriever.py:282-384).  This engine runs the same stages — dense top-k,
+BM25 top-k, optional MaxSim top-k, `_fuse`, the min_final_score filter and the
+optional rerank blend — for a whole batch of queries without leaving HBM:
+every stage is a libamdretrieval kernel launched on the caller's stream, and
+the buffers between stages are plain device allocations (torch tensors are
+used only as the allocator / stream provider).  `HybridRetriever.search_batch`
+and bench.py sit on top of it; the single-query API uses the same kernels.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from .. import _native
+
+
+@dataclass
+class BatchResult:
+    ids: torch.Tensor     # i64 [nq, max_out]  fused rank order, -1 padded
+    vals: torch.Tensor    # f64 [nq, max_out, 9]  (_native.FV layout)
+    mask: torch.Tensor    # i32 [nq, max_out]  channel membership bits
+    count: torch.Tensor   # i32 [nq]  hits surviving min_final_score
+    dense_ids: Optional[torch.Tensor] = None
+    dense_scores: Optional[torch.Tensor] = None
+    bm25_ids: Optional[torch.Tensor] = None
+    bm25_scores: Optional[torch.Tensor] = None
+    colbert_ids: Optional[torch.Tensor] = None
+    colbert_scores: Optional[torch.Tensor] = None
+    rerank: Optional[torch.Tensor] = None  # f64 [nq, max_out, 2] (raw, norm) after rerank_blend
+
+
+def _stream() -> int:
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+class HybridEngine:
+    def __init__(self, dense: Optional[_native.DenseIndex], bm25: Optional[_native.BM25Index],
+                 maxsim: Optional[_native.MaxSimIndex] = None, *, device: int = 0,
+                 dense_row2uid: Optional[torch.Tensor] = None, bm25_row2uid: Optional[torch.Tensor] = None,
+                 colbert_row2uid: Optional[torch.Tensor] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("HybridEngine needs a GPU (no CPU fallback)")
+        self.dense, self.bm25, self.maxsim = dense, bm25, maxsim
+        self.device = int(device)
+        self.tdev = torch.device("cuda", self.device)
+        self.maps = (dense_row2uid, bm25_row2uid, colbert_row2uid)
+        self._bufs = {}
+
+    def _buf(self, name, shape, dtype):
+        key = (name, tuple(shape), dtype)
+        t = self._bufs.get(key)
+        if t is None:
+            t = torch.empty(shape, dtype=dtype, device=self.tdev)
+            self._bufs[key] = t
+        return t
+
+    def reserve(self, nq: int, k: int, total_terms: int = 0) -> None:
+        if self.dense is not None:
+            self.dense.reserve(nq, k)
+        if self.bm25 is not None:
+            self.bm25.reserve(nq, k, max(total_terms, 1))
+        if self.maxsim is not None:
+            self.maxsim.reserve(nq, k)
+
+    # -- channels (device in, device out) -----------------------------------
+    def dense_topk(self, q_emb: torch.Tensor, k: int):
+        nq = q_emb.shape[0]
+        assert q_emb.is_cuda and q_emb.dtype == torch.float32 and q_emb.is_contiguous()
+        s = self._buf("ds", (nq, k), torch.float32)
+        i = self._buf("di", (nq, k), torch.int64)
+        self.dense.search_device(q_emb.data_ptr(), nq, k, s.data_ptr(), i.data_ptr(), _stream())
+        return s, i
+
+    def bm25_topk(self, q_terms: torch.Tensor, q_ptr: torch.Tensor, k: int):
+        nq = q_ptr.shape[0] - 1
+        assert q_terms.dtype == torch.int32 and q_ptr.dtype == torch.int64 and q_terms.is_cuda and q_ptr.is_cuda
+        s = self._buf("bs", (nq, k), torch.float64)
+        i = self._buf("bi", (nq, k), torch.int64)
+        self.bm25.search_device(q_terms.data_ptr(), q_ptr.data_ptr(), nq, k, s.data_ptr(), i.data_ptr(), _stream())
+        return s, i
+
+    def colbert_topk(self, q_tok: torch.Tensor, k: int):
+        nq, q_len = q_tok.shape[0], q_tok.shape[1]
+        assert q_tok.is_cuda and q_tok.dtype == torch.float32 and q_tok.is_contiguous()
+        s = self._buf("cs", (nq, k), torch.float32)
+        i = self._buf("ci", (nq, k), torch.int64)
+        self.maxsim.search_device(q_tok.data_ptr(), nq, q_len, k, s.data_ptr(), i.data_ptr(), _stream())
+        return s, i
+
+    # -- fusion ---------------------------------------------------------------
+    def fuse(self, params: _native.FuseParams, nq: int, dense=None, bm25=None, colbert=None) -> BatchResult:
+        def chan(c, m):
+            if c is None:
+                return None, 0
+            s, i = c
+            return (i.data_ptr(), s.data_ptr(), int(i.shape[1]), m.data_ptr() if m is not None else 0), int(i.shape[1])
+        d, kd = chan(dense, self.maps[0])
+        b, kb = chan(bm25, self.maps[1])
+        c, kc = chan(colbert, self.maps[2])
+        mo = kd + kb + kc
+        ids = self._buf("fi", (nq, mo), torch.int64)
+        vals = self._buf("fv", (nq, mo, _native.FUSE_NVALS), torch.float64)
+        mask = self._buf("fm", (nq, mo), torch.int32)
+        count = self._buf("fc", (nq,), torch.int32)
+        _native.fuse_device(params, nq, d, b, c, ids.data_ptr(), vals.data_ptr(), mask.data_ptr(), count.data_ptr(),
+                            device=self.device, stream=_stream())
+        return BatchResult(ids=ids, vals=vals, mask=mask, count=count)
+
+    def rerank_blend(self, res: BatchResult, ce_raw: torch.Tensor, beta: float) -> BatchResult:
+        nq, mo = res.ids.shape
+        assert ce_raw.is_cuda and ce_raw.dtype == torch.float64 and ce_raw.is_contiguous() and ce_raw.shape[0] == nq
+        out = self._buf("fr", (nq, mo, 2), torch.float64)
+        _native.rerank_blend_device(nq, mo, res.count.data_ptr(), res.ids.data_ptr(), res.vals.data_ptr(),
+                                    res.mask.data_ptr(), ce_raw.data_ptr(), int(ce_raw.shape[1]), float(beta),
+                                    out.data_ptr(), device=self.device, stream=_stream())
+        res.rerank = out
+        return res
+
+    # -- whole pipeline ---------------------------------------------------------
+    def search_batch(self, params: _native.FuseParams, k: int, *, q_emb: Optional[torch.Tensor] = None,
+                     q_terms: Optional[torch.Tensor] = None, q_ptr: Optional[torch.Tensor] = None,
+                     q_tok: Optional[torch.Tensor] = None) -> BatchResult:
+        """dense + bm25 (+ colbert) top-k -> fuse -> min_final filter, all on device."""
+        d = b = c = None
+        nq = None
+        if self.dense is not None and q_emb is not None:
+            d = self.dense_topk(q_emb, k)
+            nq = q_emb.shape[0]
+        if self.bm25 is not None and q_ptr is not None:
+            b = self.bm25_topk(q_terms, q_ptr, k)
+            nq = q_ptr.shape[0] - 1
+        if self.maxsim is not None and q_tok is not None:
+            c = self.colbert_topk(q_tok, k)
+            nq = q_tok.shape[0]
+        res = self.fuse(params, nq, d, b, c)
+        if d is not None:
+            res.dense_scores, res.dense_ids = d
+        if b is not None:
+            res.bm25_scores, res.bm25_ids = b
+        if c is not None:
+            res.colbert_scores, res.colbert_ids = c
+        return res

@@ -1,0 +1,380 @@
+"""Hybrid orchestrator: dense + BM25 (+ ColBERT) -> fusion -> filter -> rerank.
+
+Drop-in for legalrag/retrieval/hybrid_retriever.py:136-551 — same constructor
+(`HybridRetriever(cfg)`, attributes `.cfg .dense .bm25 .colbert .graph`), same
+methods (`search`, `search_dense/_bm25/_colbert/_graph`, `_fuse`), same
+RetrievalHit / score_breakdown keys, same per-stage timing log line.  The
+arithmetic of every stage runs in libamdretrieval kernels:
+    channels      dense_retriever / bm25_retriever / colbert_retriever
+    _fuse         amdr_fuse       (minmax, RRF, weighted blend, stable rank)
+    filter        amdr_fuse's min_final_score count
+    rerank blend  amdr_rerank_blend (minmax of CE scores, (1-b)s + b*norm, re-rank)
+Host Python only moves ids/scores in and out and builds the hit objects.
+`search_batch` is the throughput form (whole query batches stay in HBM).
+
+Differences from the reference, all deliberate:
+  * exactly tied fused scores keep first-appearance order (dense list, then
+    bm25, then colbert) instead of Python set-iteration order
+    (hybrid_retriever.py:460,484,526 — PYTHONHASHSEED dependent there);
+  * the graph channel is out of scope: `.graph` is always None,
+    `search_graph` returns [] and a GRAPH_AUGMENTED decision degrades to RAG.
+"""
+from __future__ import annotations
+
+import logging
+import math
+import time
+import traceback
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional, Sequence, Set, Tuple
+
+import numpy as np
+
+from .. import _native
+from ..schemas import RetrievalHit
+from .bm25_retriever import BM25Retriever
+from .colbert_retriever import ColBERTRetriever
+from .dense_retriever import DenseRetriever
+from .rerankers import RerankerFactory, _to_doc_text
+
+logger = logging.getLogger("legalrag.retrieval.hybrid_retriever")
+
+CHANNELS = ("dense", "bm25", "colbert")
+
+
+def _minmax(scores: Sequence[float]) -> List[float]:
+    """hybrid_retriever.py:24-30 (host utility; the fused path uses the kernel)."""
+    if not scores:
+        return []
+    lo, hi = min(scores), max(scores)
+    if hi - lo < 1e-12:
+        return [0.0 for _ in scores]
+    return [(float(s) - lo) / (hi - lo) for s in scores]
+
+
+def _as_channel_list(x: Any) -> List[str]:
+    if x is None:
+        return []
+    if isinstance(x, (list, set, tuple)):
+        return [str(i) for i in x]
+    return [str(x)]
+
+
+def _dedup_keep_best(hits: List[RetrievalHit]) -> List[RetrievalHit]:
+    """Best-scoring hit per chunk.id, provenance unioned (hybrid_retriever.py:71-130).
+    Channel unions are built in first-seen order (the reference goes through a set)."""
+    best: Dict[str, RetrievalHit] = {}
+    for h in hits:
+        cid = h.chunk.id
+        sb = h.score_breakdown or {}
+        if cid not in best:
+            if "channel" in sb:
+                sb["channel"] = _as_channel_list(sb.get("channel"))
+                h.score_breakdown = sb
+            best[cid] = h
+            continue
+        cur = best[cid]
+        sb_cur = cur.score_breakdown or {}
+        merged: List[str] = []
+        for c in _as_channel_list(sb_cur.get("channel")) + _as_channel_list(sb.get("channel")):
+            if c not in merged:
+                merged.append(c)
+        contrib: Dict[str, float] = {}
+        for src in (sb_cur.get("channel_contrib", {}) or {}, sb.get("channel_contrib", {}) or {}):
+            for k, v in src.items():
+                contrib[str(k)] = contrib.get(str(k), 0.0) + float(v)
+        if float(h.score) > float(cur.score):
+            best[cid] = h
+        rep = best[cid]
+        sb_rep = rep.score_breakdown or {}
+        if contrib:
+            merged.sort(key=lambda c: float(contrib.get(c, 0.0)), reverse=True)
+            sb_rep["channel_contrib"] = contrib
+        else:
+            merged.sort()
+        sb_rep["channel"] = merged
+        rep.score_breakdown = sb_rep
+    out = list(best.values())
+    out.sort(key=lambda x: float(x.score), reverse=True)
+    for i, h in enumerate(out, start=1):
+        h.rank = i
+    return out
+
+
+def _is_graph_mode(mode: Any) -> bool:
+    return bool(mode) and (str(mode).upper().endswith("GRAPH_AUGMENTED") or str(mode) == "RoutingMode.GRAPH_AUGMENTED")
+
+
+@dataclass
+class HybridRetriever:
+    cfg: Any
+
+    def __post_init__(self) -> None:
+        self.dense = DenseRetriever(self.cfg)
+        self.bm25 = BM25Retriever(self.cfg)
+        self.colbert = None
+        if getattr(self.cfg.retrieval, "enable_colbert", False):
+            try:
+                self.colbert = ColBERTRetriever.from_config(self.cfg)
+            except Exception as e:  # noqa: BLE001 - channel-level swallow, as the reference (:163-169)
+                print("[HybridRetriever] ColBERT init failed:", repr(e))
+                traceback.print_exc()
+                self.colbert = None
+        self.graph = None  # out of scope for this build (module docstring)
+
+    # ------------------------------------------------------------------ knobs
+    def _knobs(self) -> Dict[str, Any]:
+        r = self.cfg.retrieval
+        return {
+            "method": str(getattr(r, "fusion_method", "rrf_norm_blend")).lower(),
+            "rrf_k": int(getattr(r, "rrf_k", 60)),
+            "alpha": float(getattr(r, "rrf_alpha", 0.50)),
+            "weights": {"dense": float(getattr(r, "dense_weight", 0.55)), "bm25": float(getattr(r, "bm25_weight", 0.35)),
+                        "colbert": float(getattr(r, "colbert_weight", 0.25))},
+        }
+
+    def _params(self, kn: Dict[str, Any], min_final: float = -math.inf) -> "_native.FuseParams":
+        w = kn["weights"]
+        return _native.make_fuse_params(method=kn["method"], rrf_k=kn["rrf_k"], alpha=kn["alpha"], w_dense=w["dense"],
+                                        w_bm25=w["bm25"], w_colbert=w["colbert"], min_final_score=min_final)
+
+    # ------------------------------------------------------- per-channel APIs
+    def search_dense(self, question: str, top_k: int = 10) -> List[RetrievalHit]:
+        top_k = max(1, int(top_k))
+        hits = self.dense.search(question, top_k)
+        hits.sort(key=lambda h: float(h.score), reverse=True)
+        for i, h in enumerate(hits, start=1):
+            h.rank = i
+            h.source = "retriever"
+            h.score_breakdown = {"channel": ["dense"], "dense_raw": float(h.score)}
+        return hits
+
+    def search_bm25(self, question: str, top_k: int = 10) -> List[RetrievalHit]:
+        top_k = max(1, int(top_k))
+        hits = [RetrievalHit(chunk=c, score=float(s), rank=i, source="retriever",
+                             score_breakdown={"channel": ["bm25"], "bm25_raw": float(s)})
+                for i, (c, s) in enumerate(self.bm25.search(question, top_k), start=1)]
+        hits.sort(key=lambda h: float(h.score), reverse=True)
+        for i, h in enumerate(hits, start=1):
+            h.rank = i
+        return hits
+
+    def search_colbert(self, question: str, top_k: int = 10) -> List[RetrievalHit]:
+        top_k = max(1, int(top_k))
+        if self.colbert is None:
+            return []
+        try:
+            hits: List[RetrievalHit] = []
+            for item in self.colbert.search(question, top_k):
+                if isinstance(item, RetrievalHit):
+                    hits.append(item)
+                else:
+                    c, s = item
+                    hits.append(RetrievalHit(chunk=c, score=float(s), rank=0, source="retriever",
+                                             score_breakdown={"channel": ["colbert"], "colbert_raw": float(s)}))
+            hits.sort(key=lambda h: float(h.score), reverse=True)
+            for i, h in enumerate(hits, start=1):
+                h.rank = i
+                h.source = "retriever"
+                sb = h.score_breakdown or {}
+                sb["channel"] = _as_channel_list(sb.get("channel")) or ["colbert"]
+                sb.setdefault("colbert_raw", float(h.score))
+                h.score_breakdown = sb
+            return hits
+        except Exception:  # noqa: BLE001 - reference swallows channel errors (:244-245)
+            return []
+
+    def search_graph(self, question: str, top_k: int = 10, *, decision: Any = None,
+                     seeds: Optional[List[RetrievalHit]] = None) -> List[RetrievalHit]:
+        return []
+
+    # -------------------------------------------------------------- fusion
+    def _fuse(self, *, dense_hits: List[RetrievalHit], bm25_hits: List[RetrievalHit],
+              colbert_hits: List[RetrievalHit], _min_final: float = -math.inf,
+              _return_native: bool = False):
+        kn = self._knobs()
+        lists = {"dense": dense_hits, "bm25": bm25_hits, "colbert": colbert_hits}
+        for hs in lists.values():
+            hs.sort(key=lambda h: float(h.score), reverse=True)
+        # corpus-wide integer uid per chunk.id for this call; chunk lookup prefers
+        # dense -> bm25 -> colbert (setdefault order, hybrid_retriever.py:426-429)
+        uid_of: Dict[str, int] = {}
+        chunk_of: List[Any] = []
+        for h in dense_hits + bm25_hits + colbert_hits:
+            if h.chunk.id not in uid_of:
+                uid_of[h.chunk.id] = len(chunk_of)
+                chunk_of.append(h.chunk)
+        if not chunk_of:
+            return ([], None) if _return_native else []
+
+        def arr(hs: List[RetrievalHit]):
+            # a repeated id inside one channel keeps its first (best-ranked) entry
+            seen: Set[int] = set()
+            ids, sc = [], []
+            for h in hs[: _native.MAX_K]:
+                u = uid_of[h.chunk.id]
+                if u in seen:
+                    continue
+                seen.add(u)
+                ids.append(u)
+                sc.append(float(h.score))
+            if not ids:
+                return None
+            return np.asarray([ids], dtype=np.int64), np.asarray([sc], dtype=np.float64)
+
+        ids, vals, mask, count = _native.fuse(self._params(kn, _min_final), 1, arr(dense_hits), arr(bm25_hits),
+                                              arr(colbert_hits))
+        hits = self._hits_from_native(ids[0], vals[0], mask[0], ids.shape[1], kn, chunk_of)
+        if _return_native:
+            return hits, (ids, vals, mask, count)
+        return hits
+
+    @staticmethod
+    def _hits_from_native(ids, vals, mask, n, kn, chunk_of) -> List[RetrievalHit]:
+        out: List[RetrievalHit] = []
+        for r in range(int(n)):
+            if ids[r] < 0:
+                break
+            v = vals[r]
+            contrib = {ch: float(v[_native.FV["contrib_" + ch]]) for ch in CHANNELS}
+            members = [ch for c, ch in enumerate(CHANNELS) if int(mask[r]) & (1 << c)]
+            members.sort(key=lambda c: (contrib[c], c), reverse=True)
+            sb = {
+                "fusion_method": kn["method"], "rrf_k": int(kn["rrf_k"]), "alpha": float(kn["alpha"]),
+                "channel_weights": dict(kn["weights"]), "channel": members, "channel_contrib": contrib,
+                "rrf_norm": float(v[_native.FV["rrf_norm"]]), "weighted_sum": float(v[_native.FV["weighted_sum"]]),
+                "dense_norm": float(v[_native.FV["dense_norm"]]), "bm25_norm": float(v[_native.FV["bm25_norm"]]),
+                "colbert_norm": float(v[_native.FV["colbert_norm"]]),
+            }
+            out.append(RetrievalHit(chunk=chunk_of[int(ids[r])], score=float(v[_native.FV["score"]]), rank=r + 1,
+                                    source="retriever", score_breakdown=sb))
+        return out
+
+    # ---------------------------------------------------------- main search
+    def search(self, question: str, llm: Any = None, top_k: int = 10, decision: Any = None) -> List[RetrievalHit]:
+        rcfg = self.cfg.retrieval
+        top_k = max(1, int(top_k))
+        has_gpu = _native.device_count() > 0
+        t_start = time.time()
+        eff_top_k = int(getattr(rcfg, "top_k", top_k * 8) or (top_k * 8))
+        if eff_top_k < top_k:
+            eff_top_k = top_k
+
+        t0 = time.time()
+        dense_hits = self.search_dense(question, eff_top_k)
+        t1 = time.time()
+        bm25_hits = self.search_bm25(question, eff_top_k)
+        t2 = time.time()
+        colbert_hits = self.search_colbert(question, eff_top_k)
+        t3 = time.time()
+
+        min_final = float(getattr(rcfg, "min_final_score", 0.0))
+        all_fused, nat = self._fuse(dense_hits=dense_hits, bm25_hits=bm25_hits, colbert_hits=colbert_hits,
+                                    _min_final=min_final, _return_native=True)
+        kept = int(nat[3][0]) if nat is not None else 0
+        fused = all_fused[:kept]  # hits with score >= min_final_score (sorted, so a prefix)
+        t4 = time.time()
+
+        t_graph = None
+        if getattr(rcfg, "enable_graph", False) and _is_graph_mode(getattr(decision, "mode", None)):
+            # graph channel not built: the reference's `seeds + graph_hits` degenerates to the seeds
+            seed_n = int(getattr(rcfg, "graph_seed_k", max(10, top_k * 3)))
+            if self.graph is not None:
+                fused = fused[:seed_n] + self.search_graph(question, eff_top_k, decision=decision, seeds=fused[:seed_n])
+                t_graph = time.time()
+
+        t_rerank = None
+        if getattr(rcfg, "enable_rerank", False):
+            use_llm_rerank = bool(getattr(rcfg, "rerank_use_llm", False))
+            factory = RerankerFactory(llm=llm if use_llm_rerank else None, cross_model=rcfg.rerank_ce_model,
+                                      llm_threshold=30, use_cache=True)
+            rerank_top_n = int(getattr(rcfg, "rerank_top_n", min(40, max(10, top_k * 4))))
+            beta = float(getattr(rcfg, "rerank_beta", 0.35))
+            cand = fused[:rerank_top_n]
+            if cand:
+                reranker = factory.create(top_k=len(cand))
+                # the reference hands the hit objects to rerank_candidates, whose
+                # _to_doc_text turns them into str(hit) (rerankers.py:78-86) — kept.
+                docs = [_to_doc_text(h) for h in cand]
+                raw = [float(x) for x in reranker.score_batch(question, docs)]
+                fused = self._rerank_blend(fused, raw, beta)
+            t_rerank = time.time()
+
+        fused = _dedup_keep_best(fused)
+        t_end = time.time()
+
+        def ms(a, b):
+            return int((b - a) * 1000)
+        logger.info(
+            "[retrieval] dense=%dms bm25=%dms colbert=%dms fuse=%dms graph=%dms rerank=%dms total=%dms "
+            "enabled(graph=%s,colbert=%s, has_gpu=%s)",
+            ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, t_graph) if t_graph else 0,
+            ms((t_graph or t4), t_rerank) if t_rerank else 0, ms(t_start, t_end),
+            int(bool(getattr(rcfg, "enable_graph", False))), int(self.colbert is not None), int(has_gpu))
+        return fused[:top_k]
+
+    @staticmethod
+    def _rerank_blend(fused: List[RetrievalHit], raw: List[float], beta: float) -> List[RetrievalHit]:
+        """hybrid_retriever.py:343-355 on the GPU: normalise the cross-encoder
+        scores, blend, re-rank.  `raw[j]` belongs to fused[j]."""
+        n = len(fused)
+        ids = np.arange(n, dtype=np.int64)[None, :].copy()
+        vals = np.zeros((1, n, _native.FUSE_NVALS), dtype=np.float64)
+        vals[0, :, 0] = [float(h.score) for h in fused]
+        mask = np.zeros((1, n), dtype=np.int32)
+        count = np.asarray([n], dtype=np.int32)
+        rr = _native.rerank_blend(count, ids, vals, mask, np.asarray([raw], dtype=np.float64), float(beta))
+        out: List[RetrievalHit] = []
+        for r in range(n):
+            h = fused[int(ids[0, r])]
+            h.score = float(vals[0, r, 0])
+            h.rank = r + 1
+            if not math.isnan(rr[0, r, 0]):
+                h.score_breakdown = h.score_breakdown or {}
+                h.score_breakdown.update({"rerank_raw": float(rr[0, r, 0]), "rerank_norm": float(rr[0, r, 1]),
+                                          "rerank_beta": beta})
+                h.source = "rerank"
+            out.append(h)
+        return out
+
+    # ----------------------------------------------------------- batch form
+    def search_batch(self, questions: Sequence[str], top_k: int = 10) -> List[List[RetrievalHit]]:
+        """Throughput form of `search` without rerank: one kernel pipeline for the
+        whole batch (dense + BM25 (+ ColBERT) -> fuse -> filter), results built once."""
+        import torch
+        from .. import text
+        from .engine import HybridEngine
+
+        rcfg = self.cfg.retrieval
+        top_k = max(1, int(top_k))
+        eff = int(getattr(rcfg, "top_k", top_k * 8) or (top_k * 8))
+        eff = min(max(eff, top_k), _native.MAX_K)
+        self.dense.store.load()
+        self.bm25.load()
+        if len(self.dense.store.chunks) != len(self.bm25.chunks) or any(
+                a.id != b.id for a, b in zip(self.dense.store.chunks[:64], self.bm25.chunks[:64])):
+            raise RuntimeError("search_batch requires the dense and BM25 indexes to be built over the same chunk list")
+        dev = int(getattr(rcfg, "device", 0))
+        tdev = torch.device("cuda", dev)
+        eng = HybridEngine(self.dense.store.index.native, self.bm25.bm25.gpu(dev),
+                           self.colbert._searcher if self.colbert is not None else None, device=dev)
+        Q = self.dense.store._embed(list(questions), is_query=True)
+        tids = [self.bm25.bm25.term_ids(text.jieba_cut(q)) for q in questions]
+        qt, qp = _native.BM25Index.pack_queries(tids)
+        q_tok = None
+        if self.colbert is not None:
+            q_tok = torch.from_numpy(np.stack([self.colbert._encoder.encode_query(q.strip()) for q in questions])
+                                     .astype(np.float32)).to(tdev)
+        kn = self._knobs()
+        res = eng.search_batch(self._params(kn, float(getattr(rcfg, "min_final_score", 0.0))), eff,
+                               q_emb=torch.from_numpy(np.ascontiguousarray(Q)).to(tdev),
+                               q_terms=torch.from_numpy(qt).to(tdev), q_ptr=torch.from_numpy(qp).to(tdev), q_tok=q_tok)
+        torch.cuda.synchronize(tdev)
+        ids, vals, mask, cnt = (res.ids.cpu().numpy(), res.vals.cpu().numpy(), res.mask.cpu().numpy(),
+                                res.count.cpu().numpy())
+        chunks = self.dense.store.chunks
+        out = []
+        for qi in range(len(questions)):
+            hits = self._hits_from_native(ids[qi], vals[qi], mask[qi], int(cnt[qi]), kn, chunks)
+            out.append(_dedup_keep_best(hits)[:top_k])
+        return out

@@ -1,0 +1,94 @@
+"""Multi-GPU: row-sharded corpus, one process per GPU, RCCL all-gather of the
+per-shard top-k over xGMI (the reference is single-process).
+
+Rank r owns the contiguous row block [offset_r, offset_r + n_r) of every
+channel, so global id = local id + offset.  Dense, BM25 and MaxSim rows are
+independent; BM25's idf and avgdl are corpus-global statistics computed once
+and replicated (the shard's CSR keeps only its own documents).  Per query batch
+there is exactly ONE collective: every rank packs its per-channel (score bits,
+global id) lists into a single int64 buffer and all-gathers it; each rank then
+merges W*k -> k per channel (ties -> lower global id) and fuses.  The payload is
+B*k*16 bytes per channel per rank — latency-bound on xGMI, never bandwidth-bound
+— so the lever is one large collective per batch instead of one per query.
+
+`torch.distributed` is the transport (backend "nccl" == RCCL on ROCm; "gloo" on
+CPU for the world_size-2 tests).  The merge itself is the HIP kernel
+amdr_merge_topk_*; CPU tests inject a checker merge instead — the product
+default has no CPU path.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+from .. import _native
+
+
+def shard_bounds(n: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous row blocks [r*n/W, (r+1)*n/W)."""
+    return [((r * n) // world, ((r + 1) * n) // world) for r in range(world)]
+
+
+def to_global(ids: torch.Tensor, offset: int) -> torch.Tensor:
+    return torch.where(ids >= 0, ids + offset, ids)
+
+
+def pack_channels(chans: Sequence[Tuple[torch.Tensor, torch.Tensor]]) -> torch.Tensor:
+    """[(scores[nq,k_c] f32|f64, global ids[nq,k_c] i64)] -> int64 [nq, sum_c 2*k_c]."""
+    parts = []
+    for s, i in chans:
+        bits = s.to(torch.float64).view(torch.int64)  # f32 -> f64 widening is exact
+        parts += [bits, i]
+    return torch.cat(parts, dim=1).contiguous()
+
+
+def unpack_channels(buf: torch.Tensor, ks: Sequence[int], dtypes: Sequence[torch.dtype]):
+    """inverse of pack_channels on a gathered [W, nq, sum 2k] buffer."""
+    out = []
+    col = 0
+    for k, dt in zip(ks, dtypes):
+        s = buf[..., col:col + k].contiguous().view(torch.float64).to(dt).contiguous()
+        i = buf[..., col + k:col + 2 * k].contiguous()
+        out.append((s, i))
+        col += 2 * k
+    return out
+
+
+def native_merge(scores: torch.Tensor, ids: torch.Tensor, k_out: int):
+    """scores/ids [W, nq, k] on the GPU -> merged [nq, k_out] (HIP kernel)."""
+    if not scores.is_cuda:
+        raise RuntimeError("native_merge needs CUDA tensors: there is no CPU merge in the product path")
+    W, nq, k = scores.shape
+    f64 = scores.dtype == torch.float64
+    out_s = torch.empty((nq, k_out), dtype=scores.dtype, device=scores.device)
+    out_i = torch.empty((nq, k_out), dtype=torch.int64, device=scores.device)
+    _native.merge_topk_device(scores.data_ptr(), ids.data_ptr(), W, nq, k, k_out, out_s.data_ptr(), out_i.data_ptr(),
+                              f64=f64, device=scores.device.index or 0,
+                              stream=int(torch.cuda.current_stream().cuda_stream))
+    return out_s, out_i
+
+
+def exchange_topk(chans: Sequence[Tuple[torch.Tensor, torch.Tensor]], offset: int, *, group=None,
+                  merge_fn: Optional[Callable] = None):
+    """All-gather the local per-channel top-k of this rank's shard and merge.
+
+    chans: [(scores[nq,k_c], LOCAL ids[nq,k_c])].  Returns the same structure
+    holding the global top-k (global ids), identical on every rank."""
+    merge_fn = merge_fn or native_merge
+    ks = [int(i.shape[1]) for _, i in chans]
+    dts = [s.dtype for s, _ in chans]
+    local = pack_channels([(s, to_global(i, offset)) for s, i in chans])
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        gathered = local.unsqueeze(0)
+    else:
+        # concatenated-along-dim-0 output form: accepted by both RCCL and gloo
+        flat = torch.empty((world * local.shape[0], local.shape[1]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(flat, local, group=group)
+        gathered = flat.view(world, local.shape[0], local.shape[1])
+    out = []
+    for (s, i), k in zip(unpack_channels(gathered, ks, dts), ks):
+        out.append(merge_fn(s, i, k))
+    return out

@@ -1,0 +1,128 @@
+"""Dense vector backend: encoder host + exact inner-product index in HBM.
+
+Mirror of legalrag/retrieval/vector_store.py (same attributes `.index .chunks
+.index_path .meta_path .model`, same method contracts, same error types):
+  * `VectorStore(cfg)` / `from_config(cfg)`  — process-wide singleton per
+    (model, index file, meta file, device)                 (:79-93)
+  * `load()`     — mtime-guarded reload, FileNotFoundError if either file is
+    missing                                                 (:95-128)
+  * `_embed(texts, is_query)` -> float32 [n, d]; empty list -> zeros((0, d)) (:131-155)
+  * `search(query, top_k)` -> [(LawChunk, float)]           (:157-180)
+`self.index` is a faiss-shaped object (`search(q, k)`, `add(x)`, `ntotal`, `d`)
+backed by the HIP scan kernel instead of IndexHNSWFlat; HNSW knobs are accepted
+and ignored because the scan is exact.
+"""
+from __future__ import annotations
+
+import threading
+from pathlib import Path
+from typing import ClassVar, Dict, List, Tuple
+
+import numpy as np
+
+from .. import _native, artifacts, encoders
+from ..schemas import LawChunk
+
+
+class FlatIPIndex:
+    """faiss.Index-shaped facade over _native.DenseIndex."""
+
+    def __init__(self, X: np.ndarray, device: int = 0):
+        self._idx = _native.DenseIndex(X, device=device)
+        self.d = int(X.shape[1])
+        self.metric_type = artifacts.METRIC_INNER_PRODUCT
+
+    @property
+    def ntotal(self) -> int:
+        return self._idx.ntotal
+
+    def search(self, q: np.ndarray, k: int):
+        return self._idx.search(q, int(k))
+
+    def add(self, x: np.ndarray) -> None:
+        self._idx.add(x)
+
+    def reconstruct_n(self, i0: int, n: int) -> np.ndarray:
+        return self._idx.read_rows(int(i0), int(n))
+
+    @property
+    def native(self) -> "_native.DenseIndex":
+        return self._idx
+
+
+class VectorStore:
+    _instances_by_key: ClassVar[Dict[Tuple[str, str, str, str], "VectorStore"]] = {}
+    _lock: ClassVar[threading.Lock] = threading.Lock()
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        rcfg = cfg.retrieval
+        self.index_path = Path(rcfg.faiss_index_file)
+        self.meta_path = Path(rcfg.faiss_meta_file)
+        self.device_index = int(getattr(rcfg, "device", 0))
+        self.device = f"cuda:{self.device_index}"
+        self.model = encoders.get_embedder(str(rcfg.embedding_model),
+                                           backend=str(getattr(rcfg, "encoder_backend", "auto")),
+                                           dim=int(getattr(rcfg, "embedding_dim", 768)))
+        self.index: FlatIPIndex | None = None
+        self.chunks: List[LawChunk] = []
+        self._index_mtime: float | None = None
+        self._meta_mtime: float | None = None
+        self._load_lock = threading.Lock()
+
+    @classmethod
+    def from_config(cls, cfg) -> "VectorStore":
+        rcfg = cfg.retrieval
+        key = (str(rcfg.embedding_model), str(rcfg.faiss_index_file), str(rcfg.faiss_meta_file),
+               f"cuda:{int(getattr(rcfg, 'device', 0))}")
+        with cls._lock:
+            inst = cls._instances_by_key.get(key)
+            if inst is None:
+                inst = cls(cfg)
+                cls._instances_by_key[key] = inst
+            return inst
+
+    def load(self) -> None:
+        if not self.index_path.exists() or not self.meta_path.exists():
+            raise FileNotFoundError("FAISS 索引或元数据不存在，请先运行 scripts.build_index.")
+        index_mtime = self.index_path.stat().st_mtime
+        meta_mtime = self.meta_path.stat().st_mtime
+        if (self.index is not None and self.chunks and self._index_mtime == index_mtime
+                and self._meta_mtime == meta_mtime):
+            return
+        with self._load_lock:  # concurrent searches from the service thread pool
+            if (self.index is not None and self.chunks and self._index_mtime == index_mtime
+                    and self._meta_mtime == meta_mtime):
+                return
+            X, _metric = artifacts.read_faiss_index(self.index_path)
+            chunks = artifacts.read_faiss_meta(self.meta_path)
+            self.index = FlatIPIndex(X, device=self.device_index)
+            self.chunks = chunks
+            self._index_mtime = index_mtime
+            self._meta_mtime = meta_mtime
+
+    def _embed(self, texts, is_query: bool = False) -> np.ndarray:
+        if isinstance(texts, str):  # graph_retriever.py:178 calls with a bare str
+            texts = [texts]
+            single = True
+        else:
+            single = False
+        if not texts:
+            return np.zeros((0, int(self.model.hidden_size)), dtype="float32")
+        if is_query:
+            embs = self.model.encode_queries(list(texts), batch_size=64, max_length=512)
+        else:
+            embs = self.model.encode(list(texts), batch_size=64, max_length=512)
+        embs = np.asarray(embs).astype("float32")
+        return embs[0] if single else embs
+
+    def search(self, query: str, top_k: int) -> List[Tuple[LawChunk, float]]:
+        self.load()
+        q_vec = self._embed([query], is_query=True)
+        scores, idxs = self.index.search(q_vec, top_k)
+        hits: List[Tuple[LawChunk, float]] = []
+        for score, idx in zip(scores[0], idxs[0]):
+            if idx == -1:
+                continue
+            hits.append((self.chunks[idx], float(score)))
+        return hits

@@ -1,0 +1,231 @@
+"""The reference-shaped Python API on the GPU: builders -> artifacts ->
+HybridRetriever.search / _fuse / search_batch, against the oracle and against
+vectors produced by the reference's own HybridRetriever code."""
+import copy
+import logging
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden
+from helpers import assert_hits_equal_mod_ties
+
+pytestmark = pytest.mark.gpu
+
+FUSE = load_golden("fusion_golden.json")["cases"]
+SEARCH = load_golden("search_golden.json")["cases"]
+
+
+def dump(h):
+    return {"id": h.chunk.id, "score": float(h.score), "rank": h.rank, "source": h.source,
+            "breakdown": h.score_breakdown}
+
+
+def mk_chunk(i):
+    from legal_rag_amd.schemas import LawChunk
+    return LawChunk(id=f"src.txt::{i}", law_name="Synthetic Code", article_no=f"§ {i}", article_id=str(i),
+                    text=f"text of provision {i}", lang="en", source="src.txt")
+
+
+def bare_retriever(**knobs):
+    """HybridRetriever without indexes (channels injected), like the golden generator."""
+    from legal_rag_amd.config import AppConfig
+    from legal_rag_amd.retrieval.hybrid_retriever import HybridRetriever
+    cfg = AppConfig()
+    for k, v in knobs.items():
+        setattr(cfg.retrieval, k, v)
+    r = HybridRetriever.__new__(HybridRetriever)
+    r.cfg = cfg
+    r.dense = r.bm25 = r.colbert = r.graph = None
+    return r
+
+
+def hits_from(pairs, chunks, ch):
+    from legal_rag_amd.schemas import RetrievalHit
+    return [RetrievalHit(chunk=chunks[i], score=float(s), rank=r, source="retriever",
+                         score_breakdown={"channel": [ch], f"{ch}_raw": float(s)})
+            for r, (i, s) in enumerate(pairs, start=1)]
+
+
+@pytest.mark.parametrize("case", FUSE, ids=[c["name"] for c in FUSE])
+def test_product_fuse_matches_reference_vectors(case):
+    chunks = {i: mk_chunk(i) for i in range(400)}
+    r = bare_retriever(**case["knobs"])
+    out = r._fuse(dense_hits=hits_from(case["dense"], chunks, "dense"), bm25_hits=hits_from(case["bm25"], chunks, "bm25"),
+                  colbert_hits=hits_from(case["colbert"], chunks, "colbert"))
+    assert_hits_equal_mod_ties([dump(h) for h in out], case["expected"])
+
+
+class FakeDense:
+    def __init__(self, pairs, chunks):
+        self.pairs, self.chunks = pairs, chunks
+
+    def search(self, query, top_k):
+        from legal_rag_amd.schemas import RetrievalHit
+        return [RetrievalHit(chunk=self.chunks[i], score=float(s), rank=r, source="retriever", semantic_score=float(s))
+                for r, (i, s) in enumerate(self.pairs[: int(top_k)], start=1)]
+
+
+class FakePairs:
+    def __init__(self, pairs, chunks):
+        self.pairs, self.chunks = pairs, chunks
+
+    def search(self, query, top_k):
+        return [(self.chunks[i], float(s)) for i, s in self.pairs[: int(top_k)]]
+
+
+class FakeReranker:
+    def __init__(self, table):
+        self.table, self.seen = table, []
+
+    def score_batch(self, query, docs):
+        import re
+        self.seen.extend(docs)
+        return [self.table[re.search(r"LawChunk\(id='([^']+)'", d).group(1)] for d in docs]
+
+
+@pytest.mark.parametrize("case", SEARCH, ids=[c["name"] for c in SEARCH])
+def test_product_search_matches_reference_vectors(case, monkeypatch):
+    """Whole HybridRetriever.search() (channels faked exactly as in the generator):
+    same hits, scores, ranks, sources, breakdowns — and the SAME strings handed to
+    the cross-encoder (the str(hit) quirk)."""
+    from legal_rag_amd.retrieval import hybrid_retriever as hr
+    chunks = {i: mk_chunk(i) for i in range(300)}
+    r = bare_retriever(**case["knobs"])
+    r.dense = FakeDense(case["dense"], chunks)
+    r.bm25 = FakePairs(case["bm25"], chunks)
+    r.colbert = FakePairs(case["colbert"], chunks) if case["colbert"] else None
+    fake = FakeReranker(case["ce_raw_by_id"])
+    monkeypatch.setattr(hr.RerankerFactory, "create", lambda self, top_k: fake)
+    out = r.search("synthetic question", llm=None, top_k=case["top_k"], decision=None)
+    assert_hits_equal_mod_ties([dump(h) for h in out], case["expected"])
+    assert fake.seen == case["ce_docs_seen"]
+
+
+# ---------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def ucc_index(tmp_path_factory):
+    """Build the UCC-en indexes with the product builders (stand-in encoders)."""
+    from legal_rag_amd.config import AppConfig
+    from legal_rag_amd.retrieval.builders.bm25_builder import build_bm25_index
+    from legal_rag_amd.retrieval.builders.colbert_builder import build_colbert_index
+    from legal_rag_amd.retrieval.builders.faiss_builder import build_faiss_index
+    from legal_rag_amd.retrieval.corpus_loader import load_chunks_from_dir
+    data = tmp_path_factory.mktemp("data")
+    cfg = AppConfig.for_data_dir(str(data), "en")
+    cfg.retrieval.encoder_backend = "hashing"
+    chunks = load_chunks_from_dir(str(GOLDEN / "corpus"), "law_en.jsonl")[:200]
+    build_faiss_index(cfg, chunks)
+    build_bm25_index(cfg, chunks)
+    build_colbert_index(cfg, chunks)
+    return cfg, chunks
+
+
+def oracle_channels(cfg, chunks, question, k):
+    from legal_rag_amd import encoders, text
+    from oracle import bm25 as OB
+    from oracle import dense as OD
+    from oracle import maxsim as OM
+    emb = encoders.HashingEmbedder(768)
+    X = emb.encode([c.text for c in chunks])
+    q = emb.encode_queries([question])
+    ds, di = OD.flatip_topk(X, q, k)
+    ob = OB.BM25Okapi([OB.tokenize_en(c.text) for c in chunks])
+    b = OB.search(ob, text.jieba_cut(question), k)
+    te = encoders.HashingTokenEmbedder()
+    mats = [te.encode_doc(c.text.strip()) for c in chunks]
+    ptr = np.concatenate([[0], np.cumsum([m.shape[0] for m in mats])])
+    cs, ci = OM.maxsim_topk(te.encode_query(question.strip())[None], np.concatenate(mats), ptr, k)
+    return ([(chunks[i].id, float(s)) for s, i in zip(ds[0], di[0]) if i >= 0],
+            [(chunks[i].id, s) for i, s in b],
+            [(chunks[i].id, float(s)) for s, i in zip(cs[0], ci[0]) if i >= 0])
+
+
+QUESTIONS = ["what warranty does a merchant give that goods are merchantable",
+             "Short Titles", "statute of frauds signed writing sale of goods price of $500",
+             "What is § 2-314?", "risk of loss passes to the buyer on tender of delivery"]
+
+
+@pytest.mark.parametrize("question", QUESTIONS)
+def test_end_to_end_search_matches_oracle(ucc_index, question, monkeypatch, caplog):
+    from legal_rag_amd import encoders
+    from legal_rag_amd.retrieval import hybrid_retriever as hr
+    from oracle import fusion as OF
+    cfg, chunks = ucc_index
+    ce = encoders.HashingCrossScorer()
+    monkeypatch.setattr(hr.RerankerFactory, "create", lambda self, top_k: ce)
+    r = hr.HybridRetriever(cfg)
+    assert r.colbert is not None and r.colbert.enabled
+    with caplog.at_level(logging.INFO, logger="legalrag.retrieval.hybrid_retriever"):
+        hits = r.search(question, top_k=10)
+    assert any("[retrieval] dense=" in m and "rerank=" in m for m in caplog.messages)
+    d, b, c = oracle_channels(cfg, chunks, question, 10)
+    # per-channel parity: bm25 bit-exact, dense / colbert within 1e-4
+    gb = r.search_bm25(question, 10)
+    assert [(h.chunk.id, h.score) for h in gb] == b
+    gd = r.search_dense(question, 10)
+    assert [h.chunk.id for h in gd] == [i for i, _ in d]
+    assert np.allclose([h.score for h in gd], [s for _, s in d], atol=1e-4)
+    gc = r.search_colbert(question, 10)
+    assert [h.chunk.id for h in gc] == [i for i, _ in c]
+    assert np.allclose([h.score for h in gc], [s for _, s in c], atol=1e-4)
+    # orchestration: run the oracle's search() on the GPU channel outputs (identical
+    # inputs -> bit-exact fusion / rerank), with the CE scoring the same str(hit) text
+    by_id = {x.id: x for x in chunks}
+    fused_for_text = {h.chunk.id: h for h in r._fuse(dense_hits=r.search_dense(question, 10),
+                                                     bm25_hits=r.search_bm25(question, 10),
+                                                     colbert_hits=r.search_colbert(question, 10))}
+    exp = OF.search([(h.chunk.id, h.score) for h in gd], [(h.chunk.id, h.score) for h in gb],
+                    [(h.chunk.id, h.score) for h in gc], top_k=10, knobs={},
+                    ce_score=lambda ids: ce.score_batch(question, [str(fused_for_text[i]) for i in ids]))
+    assert_hits_equal_mod_ties([dump(h) for h in hits], exp)
+    assert all(h.chunk is by_id[h.chunk.id] or h.chunk == by_id[h.chunk.id] for h in hits)
+
+
+def test_search_batch_equals_single_queries(ucc_index):
+    from legal_rag_amd.retrieval.hybrid_retriever import HybridRetriever
+    cfg, _ = ucc_index
+    cfg2 = copy.deepcopy(cfg)
+    cfg2.retrieval.enable_rerank = False
+    r = HybridRetriever(cfg2)
+    batch = r.search_batch(QUESTIONS, top_k=10)
+    for q, got in zip(QUESTIONS, batch):
+        exp = r.search(q, top_k=10)
+        assert [h.chunk.id for h in got] == [h.chunk.id for h in exp]
+        assert [h.score for h in got] == [h.score for h in exp]
+        assert [h.score_breakdown for h in got] == [h.score_breakdown for h in exp]
+
+
+def test_error_conventions(tmp_path):
+    """Missing dense files -> FileNotFoundError; missing bm25 -> RuntimeError;
+    missing colbert meta is swallowed at construction."""
+    from legal_rag_amd.config import AppConfig
+    from legal_rag_amd.retrieval.hybrid_retriever import HybridRetriever
+    cfg = AppConfig.for_data_dir(str(tmp_path), "en")
+    cfg.retrieval.encoder_backend = "hashing"
+    r = HybridRetriever(cfg)
+    assert r.colbert is None
+    with pytest.raises(FileNotFoundError):
+        r.search_dense("x", 3)
+    with pytest.raises(RuntimeError):
+        r.search_bm25("x", 3)
+    assert r.search_colbert("x", 3) == [] and r.search_graph("x") == []
+
+
+def test_reference_built_style_artifacts_load(tmp_path):
+    """A bm25.pkl naming rank_bm25.BM25Okapi and a faiss.index in FAISS's container
+    format load and search (artifact compatibility)."""
+    from legal_rag_amd import artifacts
+    from legal_rag_amd.config import AppConfig
+    from legal_rag_amd.retrieval.bm25_retriever import BM25Retriever
+    from legal_rag_amd.retrieval.builders.bm25_builder import build_bm25_index
+    from legal_rag_amd.retrieval.corpus_loader import load_chunks_from_dir
+    cfg = AppConfig.for_data_dir(str(tmp_path), "en")
+    chunks = load_chunks_from_dir(str(GOLDEN / "corpus"), "law_en.jsonl")[:50]
+    build_bm25_index(cfg, chunks)
+    assert b"rank_bm25" in open(cfg.retrieval.bm25_index_file, "rb").read()
+    br = BM25Retriever(cfg)
+    got = br.search("seller goods", 5)
+    from oracle import bm25 as OB
+    ob = OB.BM25Okapi([OB.tokenize_en(c.text) for c in chunks])
+    assert [(c.id, s) for c, s in got] == [(chunks[i].id, s) for i, s in OB.search(ob, ["seller", " ", "goods"], 5)]

@@ -1,0 +1,145 @@
+"""Host-side pieces of the product (no GPU): BM25 statistics, config layout,
+rerank utilities, dedup, evaluation metrics — against the oracle / goldens."""
+import copy
+import math
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden
+from legal_rag_amd import evaluation
+from legal_rag_amd.bm25_model import BM25Okapi
+from legal_rag_amd.config import AppConfig
+from legal_rag_amd.retrieval import rerankers
+from legal_rag_amd.retrieval.corpus_loader import load_chunks_from_dir
+from legal_rag_amd.schemas import LawChunk, RetrievalHit
+from legal_rag_amd.text import tokenize_en
+from oracle import bm25 as OB
+
+UTIL = load_golden("util_golden.json")
+
+
+@pytest.fixture(scope="module")
+def ucc():
+    return load_chunks_from_dir(str(GOLDEN / "corpus"), "law_en.jsonl")
+
+
+def test_corpus_statistics_regression(ucc):
+    """SURVEY.md §8c(5) / BASELINE.md §2: 592 parsed, 591 unique (dup id ucc_4A.txt::4A-102)."""
+    raw = [l for l in (GOLDEN / "corpus" / "law_en.jsonl").read_text(encoding="utf-8").splitlines() if l.strip()]
+    assert len(raw) == 592 and len(ucc) == 591
+    import json
+    ids = [json.loads(l)["id"] for l in raw]
+    assert sorted({i for i in ids if ids.count(i) > 1}) == ["ucc_4A.txt::4A-102"]
+    toks_all = [tokenize_en(json.loads(l)["text"]) for l in raw]
+    assert sum(len(t) for t in toks_all) == 148124
+    bm = BM25Okapi(toks_all)
+    assert len(bm.idf) == 3926 and sum(len(d) for d in bm.doc_freqs) == 54010 and max(bm.doc_len) == 4550
+    zh = load_chunks_from_dir(str(GOLDEN / "corpus"), "law_zh.jsonl")
+    assert len(zh) == 1260
+
+
+def test_product_bm25_statistics_equal_oracle(ucc):
+    toks = [tokenize_en(c.text) for c in ucc]
+    a, b = BM25Okapi(toks), OB.BM25Okapi(toks)
+    assert a.avgdl == b.avgdl and a.average_idf == b.average_idf and a.corpus_size == b.corpus_size
+    assert list(a.idf.items()) == list(b.idf.items())  # same order, bit-equal values
+    ca, cb = a.to_csr(), OB.to_csr(b)
+    for x, key in zip(ca, ("term_ptr", "post_doc", "post_tf", "idf", "doc_len")):
+        assert np.array_equal(x, cb[key]), key
+    assert a.term_ids(["the", "Buyer", "zzz"]) == [b_ for b_ in (cb["vocab"]["the"], -1, -1)]
+
+
+def test_negative_idf_floor():
+    docs = [["a", "b"], ["a"], ["a", "c"], ["a"]]
+    bm = BM25Okapi(docs)
+    raw = math.log(4 - 4 + 0.5) - math.log(4 + 0.5)
+    assert raw < 0 and bm.idf["a"] == 0.25 * bm.average_idf
+    assert bm.idf == OB.BM25Okapi(docs).idf
+
+
+def test_config_layout_and_registry(tmp_path):
+    cfg = AppConfig.for_data_dir(str(tmp_path), "en")
+    r = cfg.retrieval
+    root = tmp_path / "index" / "en"
+    assert r.faiss_index_file == str(root / "faiss" / "faiss.index")
+    assert r.faiss_meta_file == str(root / "faiss" / "faiss_meta.jsonl")
+    assert r.bm25_index_file == str(root / "bm25.pkl")
+    assert r.colbert_meta_file == str(root / "colbert" / "colbert_meta.jsonl")
+    assert r.embedding_model == r.embedding_model_en and r.colbert_index_name == "law_en"
+    assert not root.exists()  # constructing a config creates nothing
+    (root / "versions" / "v2").mkdir(parents=True)
+    (root / "ACTIVE").write_text("v2")
+    assert cfg.with_lang("en").retrieval.bm25_index_file == str(root / "versions" / "v2" / "bm25.pkl")
+    (root / "ACTIVE").write_text("missing")
+    assert cfg.with_lang("en").retrieval.bm25_index_file == str(root / "bm25.pkl")
+    zh = cfg.with_lang("zh")
+    assert zh.retrieval.embedding_model == zh.retrieval.embedding_model_zh and "index/zh" in zh.retrieval.bm25_index_file
+    # reference defaults of the knobs the path reads (legalrag/config.py:92-129)
+    assert (r.top_k, r.dense_weight, r.bm25_weight, r.colbert_weight, r.min_final_score) == (10, 0.6, 0.4, 0.35, 0.2)
+    assert (r.rerank_top_n, r.rrf_alpha, r.rerank_beta, r.rrf_k, r.fusion_method) == (30, 0.5, 0.35, 60, "rrf_norm_blend")
+
+
+def test_rerank_utils_match_reference_vectors():
+    for row in UTIL["minmax"]:
+        assert rerankers.minmax_normalize(row["in"]) == row["rerank_minmax"]
+    rn = UTIL["rerank_norm"]
+    assert [rerankers.sigmoid(x) for x in rn["x"]] == rn["sigmoid"]
+    assert rerankers.sigmoid_calibrate(rn["x"], 0.25) == rn["calibrate_t0p25"]
+    assert rerankers.sigmoid_calibrate(rn["x"], 0.0) == rn["calibrate_t0"]
+
+    class Fake:
+        def __init__(self, t):
+            self.t = t
+
+        def score_batch(self, q, docs):
+            return [self.t[d] for d in docs]
+    for case in UTIL["rerank_candidates"]:
+        cands = [{"text": f"doc {i}", "id": i} for i in range(9)]
+        res = rerankers.rerank_candidates("q", cands, Fake(case["raw_by_text"]), top_n=case["top_n"],
+                                          normalize=case["normalize"], sigmoid_temperature=0.5, include_debug=True)
+        got = [{"id": c["id"], "raw": r.raw_score, "norm": r.norm_score, "meta": r.meta} for c, r in res]
+        assert got == case["expected"]
+
+
+def test_rerank_doc_text_quirk():
+    """Hits are neither str nor dict -> the cross-encoder sees str(hit) (rerankers.py:78-86)."""
+    c = LawChunk(id="a::1", law_name="L", article_no="§ 1", article_id="1", text="T", lang="en")
+    h = RetrievalHit(chunk=c, score=0.5, rank=1)
+    s = rerankers._to_doc_text(h)
+    assert s.startswith("chunk=LawChunk(id='a::1', law_name='L', chapter=None, section=None, article_no='§ 1', "
+                        "article_id='1', text='T', lang='en', source=None, start_char=None, end_char=None) score=0.5 "
+                        "rank=1 source='retriever'")
+    assert rerankers._to_doc_text({"content": "x"}) == "x" and rerankers._to_doc_text("y") == "y"
+
+
+def test_dedup_keep_best_matches_reference_vectors():
+    from legal_rag_amd.retrieval.hybrid_retriever import _dedup_keep_best
+    for row in UTIL["dedup"]:
+        hits = []
+        for h in copy.deepcopy(row["in"]):
+            i = h["id"].split("::")[1]
+            c = LawChunk(id=h["id"], law_name="Synthetic Code", article_no=f"§ {i}", article_id=i, text="t", lang="en")
+            hits.append(RetrievalHit(chunk=c, score=h["score"], rank=h["rank"], score_breakdown=h["breakdown"]))
+        got = _dedup_keep_best(hits)
+        exp = row["expected"]
+        assert [g.chunk.id for g in got] == [e["id"] for e in exp]
+        for g, e in zip(got, exp):
+            assert g.score == e["score"] and g.rank == e["rank"]
+            gb, eb = g.score_breakdown or {}, e["breakdown"] or {}
+            assert gb.get("channel_contrib") == eb.get("channel_contrib")
+            assert sorted(gb.get("channel", [])) == sorted(eb.get("channel", []))
+
+
+def test_metrics():
+    pred = ["a", "b", "c", "d"]
+    assert evaluation.recall_at_k(pred, {"c"}, 3) == 1.0 and evaluation.recall_at_k(pred, {"c"}, 2) == 0.0
+    assert evaluation.mrr_at_k(pred, {"b"}, 10) == 0.5 and evaluation.hit_at_k(pred, {"z"}, 10) == 0.0
+    assert abs(evaluation.ndcg_at_k(pred, {"b"}, 10) - 1 / math.log2(3)) < 1e-15
+    assert evaluation.recall_at_k(pred, set(), 5) == 0.0
+
+
+def test_synthetic_queries_are_deterministic(ucc):
+    a = evaluation.synthetic_queries(ucc, seed=0)
+    assert a == evaluation.synthetic_queries(ucc, seed=0) and len(a) == 1168
+    assert a[0] == ("Short Titles", "1-101", "title")
