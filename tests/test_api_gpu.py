@@ -99,7 +99,17 @@ def test_product_search_matches_reference_vectors(case, monkeypatch):
     monkeypatch.setattr(hr.RerankerFactory, "create", lambda self, top_k: fake)
     out = r.search("synthetic question", llm=None, top_k=case["top_k"], decision=None)
     assert_hits_equal_mod_ties([dump(h) for h in out], case["expected"])
-    assert fake.seen == case["ce_docs_seen"]
+    if fake.seen != case["ce_docs_seen"]:
+        # exactly tied fused scores may swap places (set-order in the reference): the same
+        # strings up to the rank number inside them, in the same order up to those swaps
+        import re
+
+        def norm(xs):
+            return sorted(re.sub(r" rank=\d+ ", " rank=? ", s) for s in xs)
+        assert norm(fake.seen) == norm(case["ce_docs_seen"])
+        scores_g = [re.search(r" score=(\S+) ", s).group(1) for s in fake.seen]
+        scores_e = [re.search(r" score=(\S+) ", s).group(1) for s in case["ce_docs_seen"]]
+        assert scores_g == scores_e
 
 
 # ---------------------------------------------------------------------------
