@@ -33,17 +33,23 @@ __device__ __forceinline__ long lower_bound_i32(const int* __restrict__ a, long 
   return lo;
 }
 
-// grid: (x = doc slabs, y = queries).  LDS: double sc[slab] + C64 lists[4][cap] + int cnts[4]
-__global__ __launch_bounds__(256) void bm25_score_topk_kernel(
+// grid: (x = doc slabs, y = queries).  LDS: double sc[slab] + C64 lists[WAVES][cap] + int cnts[WAVES]
+// WAVES = 1 for small slabs (one wave per query: no block barriers, no list combine),
+// 4 for full 4096-doc slabs.  With a single slab the final (scores, ids) are written
+// directly and the merge launch is skipped.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void bm25_score_topk_kernel(
     const long long* __restrict__ term_ptr, const int* __restrict__ post_doc, const int* __restrict__ post_tf,
     const double* __restrict__ idf, const int* __restrict__ doc_len, long n_terms, long n_docs, double avgdl,
     double k1, double k1p1, double one_minus_b, double b, const int* __restrict__ q_terms,
     const long long* __restrict__ q_ptr, int nq, int k, int cap, int slab,
-    double* __restrict__ scores_out /* nullable [nq, n_docs] */, C64* __restrict__ part /* nullable [nslabs][nq][k] */) {
+    double* __restrict__ scores_out /* nullable [nq, n_docs] */, C64* __restrict__ part /* nullable [nslabs][nq][k] */,
+    double* __restrict__ fin_scores /* nullable [nq,k]: single slab */, long long* __restrict__ fin_ids) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* sc = reinterpret_cast<double*>(smem);
   C64* lists = reinterpret_cast<C64*>(sc + slab);
-  int* cnts = reinterpret_cast<int*>(lists + (size_t)kBmWaves * cap);
+  int* cnts = reinterpret_cast<int*>(lists + (size_t)WAVES * cap);
+  constexpr int NT = WAVES * 64;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qi = blockIdx.y;
@@ -52,8 +58,8 @@ __global__ __launch_bounds__(256) void bm25_score_topk_kernel(
   if (hi > n_docs) hi = n_docs;
   const int m = (int)(hi - lo);
 
-  for (int i = tid; i < m; i += 256) sc[i] = 0.0;
-  __syncthreads();
+  for (int i = tid; i < m; i += NT) sc[i] = 0.0;
+  block_sync<WAVES>();
 
   const long t0 = q_ptr[qi], t1 = q_ptr[qi + 1];
   for (long t = t0; t < t1; ++t) {
@@ -62,7 +68,7 @@ __global__ __launch_bounds__(256) void bm25_score_topk_kernel(
     const long p0 = term_ptr[term], p1 = term_ptr[term + 1];
     const long ps = (lo == 0) ? p0 : lower_bound_i32(post_doc, p0, p1, (int)lo);
     const double w = idf[term];
-    for (long p = ps + tid; p < p1; p += 256) {
+    for (long p = ps + tid; p < p1; p += NT) {
       const int doc = post_doc[p];
       if (doc >= hi) break;
       const double qf = (double)post_tf[p];
@@ -71,27 +77,35 @@ __global__ __launch_bounds__(256) void bm25_score_topk_kernel(
       const double denom = qf + k1 * (one_minus_b + b * dl / avgdl);
       sc[doc - lo] += w * (qf * k1p1 / denom);
     }
-    __syncthreads();
+    block_sync<WAVES>();
   }
 
   if (scores_out) {
-    for (int i = tid; i < m; i += 256) scores_out[(size_t)qi * n_docs + lo + i] = sc[i];
+    for (int i = tid; i < m; i += NT) scores_out[(size_t)qi * n_docs + lo + i] = sc[i];
   }
-  if (!part) return;
+  if (!part && !fin_ids) return;
 
   WaveTopK<C64> tk;
   tk.init(lists + (size_t)wave * cap, cap, k);
-  for (int base = wave * 64; base < m; base += kBmWaves * 64) {
+  for (int base = wave * 64; base < m; base += WAVES * 64) {
     int i = base + lane;
     bool v = i < m;
     C64 c = v ? C64::make(sc[i], lo + i) : C64::pad();
     tk.push_lanes(c, v, lane);
   }
   tk.finalize(lane);
-  block_combine_topk(tk, lists, cap, kBmWaves, wave, lane, cnts);
+  if (WAVES > 1) block_combine_topk(tk, lists, cap, WAVES, wave, lane, cnts);
   if (wave == 0) {
-    C64* dst = part + ((size_t)blockIdx.x * nq + qi) * k;
-    for (int j = lane; j < k; j += 64) dst[j] = (j < tk.cnt) ? tk.buf[j] : C64::pad();
+    if (fin_ids) {
+      for (int j = lane; j < k; j += 64) {
+        bool v = j < tk.cnt;
+        fin_scores[(size_t)qi * k + j] = v ? unord64(tk.buf[j].key) : -DBL_MAX;
+        fin_ids[(size_t)qi * k + j] = v ? tk.buf[j].idv : -1ll;
+      }
+    } else {
+      C64* dst = part + ((size_t)blockIdx.x * nq + qi) * k;
+      for (int j = lane; j < k; j += 64) dst[j] = (j < tk.cnt) ? tk.buf[j] : C64::pad();
+    }
   }
 }
 
@@ -152,7 +166,7 @@ namespace {
 constexpr int kSlabMax = 4096;  // docs per block: 32 KiB of fp64 scores in LDS
 
 struct BmPlan {
-  int slab, nslabs, cap;
+  int slab, nslabs, cap, waves;
   size_t lds, part_bytes;
 };
 
@@ -160,7 +174,8 @@ void bm_plan(int64_t n_docs, int nq, int k, BmPlan* p) {
   p->cap = topk_cap(k);
   p->slab = n_docs < kSlabMax ? (int)(n_docs > 0 ? n_docs : 1) : kSlabMax;
   p->nslabs = n_docs > 0 ? (int)((n_docs + p->slab - 1) / p->slab) : 1;
-  p->lds = (size_t)p->slab * sizeof(double) + (size_t)kBmWaves * p->cap * sizeof(C64) + kBmWaves * sizeof(int);
+  p->waves = p->slab <= 1024 ? 1 : kBmWaves;
+  p->lds = (size_t)p->slab * sizeof(double) + (size_t)p->waves * p->cap * sizeof(C64) + p->waves * sizeof(int);
   p->part_bytes = (size_t)p->nslabs * nq * k * sizeof(C64);
 }
 
@@ -174,11 +189,20 @@ int bm_run(amdr_bm25* h, const int* q_terms_dev, const long long* q_ptr_dev, int
     if (rc) return rc;
     part = h->part.as<C64>();
   }
-  hipLaunchKernelGGL(bm25_score_topk_kernel, dim3(p.nslabs, nq), dim3(256), p.lds, st, h->term_ptr, h->post_doc,
-                     h->post_tf, h->idf, h->doc_len, (long)h->n_terms, (long)h->n_docs, h->avgdl, h->k1, h->k1 + 1,
-                     1 - h->b, h->b, q_terms_dev, q_ptr_dev, nq, k, p.cap, p.slab, full_dev, part);
+  const bool direct = scores_dev && p.nslabs == 1;  // single slab: the block's list is the answer
+  double* fs = direct ? scores_dev : nullptr;
+  long long* fi = direct ? (long long*)ids_dev : nullptr;
+  if (direct) part = nullptr;
+  if (p.waves == 1)
+    hipLaunchKernelGGL(bm25_score_topk_kernel<1>, dim3(p.nslabs, nq), dim3(64), p.lds, st, h->term_ptr, h->post_doc,
+                       h->post_tf, h->idf, h->doc_len, (long)h->n_terms, (long)h->n_docs, h->avgdl, h->k1, h->k1 + 1,
+                       1 - h->b, h->b, q_terms_dev, q_ptr_dev, nq, k, p.cap, p.slab, full_dev, part, fs, fi);
+  else
+    hipLaunchKernelGGL(bm25_score_topk_kernel<kBmWaves>, dim3(p.nslabs, nq), dim3(256), p.lds, st, h->term_ptr,
+                       h->post_doc, h->post_tf, h->idf, h->doc_len, (long)h->n_terms, (long)h->n_docs, h->avgdl, h->k1,
+                       h->k1 + 1, 1 - h->b, h->b, q_terms_dev, q_ptr_dev, nq, k, p.cap, p.slab, full_dev, part, fs, fi);
   AMDR_HIP(hipGetLastError());
-  if (scores_dev) {
+  if (scores_dev && !direct) {
     size_t lds = (size_t)kBmWaves * p.cap * sizeof(C64) + kBmWaves * sizeof(int);
     hipLaunchKernelGGL(bm25_merge_kernel, dim3(nq), dim3(256), lds, st, part, p.nslabs, nq, k, p.cap, scores_dev,
                        (long long*)ids_dev);

@@ -65,4 +65,17 @@ inline int topk_cap(int k) { return next_pow2(k + 64) < 128 ? 128 : next_pow2(k 
 
 int check_device(int device);
 
+// ---- batched (32-query tile, fp32 MFMA) dense path: dense_mfma.hip -----------
+struct DenseMfmaPlan {
+  int q_tiles, grid_x, slabs, cap;
+  long rows_per_block, rows_per_slab;
+  size_t lds_scores, s_bytes, part_bytes;
+};
+bool dense_mfma_supported(int d);
+void dense_mfma_plan(long n, int d, int nq, int k, DenseMfmaPlan* p);
+int dense_mfma_launch_scores(const DenseMfmaPlan& p, const float* X, long n, int d, const float* Q, int nq, float* S,
+                             hipStream_t st);
+int dense_mfma_launch_topk(const DenseMfmaPlan& p, const float* S, long n, int nq, int k, void* part,
+                           float* fin_scores, int64_t* fin_ids, hipStream_t st);
+
 }  // namespace amdr

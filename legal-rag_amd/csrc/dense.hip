@@ -50,7 +50,9 @@ template <int NQ, int CH, int U>
 __global__ __launch_bounds__(256) void dense_scan_topk_kernel(const float* __restrict__ X, long n, int d,
                                                                const float* __restrict__ Q, int nq_total, int k,
                                                                int cap, long rows_per_block,
-                                                               C32* __restrict__ part /*[gridDim.x][nq_total][k]*/) {
+                                                               C32* __restrict__ part /*[gridDim.x][nq_total][k]*/,
+                                                               float* __restrict__ fin_scores /* single slab */,
+                                                               long long* __restrict__ fin_ids) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   C32* lists = reinterpret_cast<C32*>(smem);
   int* cnts = reinterpret_cast<int*>(lists + (size_t)kWaves * NQ * cap);
@@ -113,8 +115,17 @@ __global__ __launch_bounds__(256) void dense_scan_topk_kernel(const float* __res
   for (int b = 0; b < NQ; ++b) {
     block_combine_topk(tk[b], lists + (size_t)b * kWaves * cap, cap, kWaves, wave, lane, cnts);
     if (wave == 0 && qbase + b < nq_total) {
-      C32* dst = part + ((size_t)blockIdx.x * nq_total + (qbase + b)) * k;
-      for (int j = lane; j < k; j += 64) dst[j] = (j < tk[b].cnt) ? tk[b].buf[j] : C32::pad();
+      if (fin_ids) {  // single slab: this list is the final answer, no merge launch follows
+        for (int j = lane; j < k; j += 64) {
+          const bool v = j < tk[b].cnt;
+          const C32 c = v ? tk[b].buf[j] : C32::pad();
+          fin_scores[(size_t)(qbase + b) * k + j] = v ? c.score() : -FLT_MAX;
+          fin_ids[(size_t)(qbase + b) * k + j] = v ? c.id() : -1ll;
+        }
+      } else {
+        C32* dst = part + ((size_t)blockIdx.x * nq_total + (qbase + b)) * k;
+        for (int j = lane; j < k; j += 64) dst[j] = (j < tk[b].cnt) ? tk[b].buf[j] : C32::pad();
+      }
     }
     __syncthreads();
   }
@@ -227,7 +238,7 @@ struct amdr_dense {
   bool owns = true;
   hipStream_t stream = nullptr;
   std::mutex mu;
-  DevBuf part, qbuf, sbuf, ibuf;
+  DevBuf part, qbuf, sbuf, ibuf, smat;
   // optional HIP-event ring bracketing the scan kernel alone (bench.py roofline)
   std::vector<hipEvent_t> prof_ev;
   int prof_used = 0;
@@ -279,26 +290,77 @@ int make_plan(int64_t n, int d, int nq, int k, ScanPlan* p) {
 }
 
 template <int NQ, int CH>
-void launch_scan(const ScanPlan& p, const amdr_dense* h, const float* Q, int nq, int k, C32* part, hipStream_t st) {
+void launch_scan(const ScanPlan& p, const amdr_dense* h, const float* Q, int nq, int k, C32* part, float* fs,
+                 int64_t* fi, hipStream_t st) {
   constexpr int U = (NQ <= 2) ? 4 : 2;
   hipLaunchKernelGGL((dense_scan_topk_kernel<NQ, CH, U>), dim3(p.grid_x, p.grid_y), dim3(256), p.lds, st, h->X,
-                     (long)h->n, h->d, Q, nq, k, p.cap, p.rows_per_block, part);
+                     (long)h->n, h->d, Q, nq, k, p.cap, p.rows_per_block, part, fs, (long long*)fi);
 }
 
 template <int NQ>
-int launch_scan_ch(const ScanPlan& p, const amdr_dense* h, const float* Q, int nq, int k, C32* part, hipStream_t st) {
+int launch_scan_ch(const ScanPlan& p, const amdr_dense* h, const float* Q, int nq, int k, C32* part, float* fs,
+                   int64_t* fi, hipStream_t st) {
   switch (p.ch) {
-    case 1: launch_scan<NQ, 1>(p, h, Q, nq, k, part, st); break;
-    case 2: launch_scan<NQ, 2>(p, h, Q, nq, k, part, st); break;
-    case 3: launch_scan<NQ, 3>(p, h, Q, nq, k, part, st); break;
-    case 4: launch_scan<NQ, 4>(p, h, Q, nq, k, part, st); break;
+    case 1: launch_scan<NQ, 1>(p, h, Q, nq, k, part, fs, fi, st); break;
+    case 2: launch_scan<NQ, 2>(p, h, Q, nq, k, part, fs, fi, st); break;
+    case 3: launch_scan<NQ, 3>(p, h, Q, nq, k, part, fs, fi, st); break;
+    case 4: launch_scan<NQ, 4>(p, h, Q, nq, k, part, fs, fi, st); break;
     default: return fail(AMDR_EINVAL, "dense: unsupported dim %d", h->d);
+  }
+  return AMDR_OK;
+}
+
+// Batches of >= kBatchedMin queries take the 32-query-tile MFMA path (dense_mfma.hip);
+// the score matrix workspace is bounded, so very large batches go in chunks of queries.
+constexpr int kBatchedMin = 12;
+constexpr size_t kScoreBytesMax = (size_t)4 << 30;
+
+int batched_chunk(const amdr_dense* h, int nq) {
+  size_t per_q = (size_t)h->n * sizeof(float);
+  long c = (long)(kScoreBytesMax / (per_q ? per_q : 1));
+  c = (c / 32) * 32;
+  if (c < 32) c = 32;
+  return nq < c ? nq : (int)c;
+}
+
+int run_search_batched(amdr_dense* h, const float* Q_dev, int nq, int k, float* scores_dev, int64_t* ids_dev,
+                       hipStream_t st) {
+  const int chunk = batched_chunk(h, nq);
+  DenseMfmaPlan p;
+  dense_mfma_plan((long)h->n, h->d, chunk, k, &p);
+  int rc = h->smat.ensure(p.s_bytes);
+  if (!rc) rc = h->part.ensure(p.part_bytes);
+  if (rc) return rc;
+  for (int q0 = 0; q0 < nq; q0 += chunk) {
+    const int m = nq - q0 < chunk ? nq - q0 : chunk;
+    if (m != chunk) dense_mfma_plan((long)h->n, h->d, m, k, &p);
+    const bool prof = h->prof_on && (size_t)(h->prof_used + 2) <= h->prof_ev.size();
+    if (prof) AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
+    rc = dense_mfma_launch_scores(p, h->X, (long)h->n, h->d, Q_dev + (size_t)q0 * h->d, m, h->smat.as<float>(), st);
+    if (rc) return rc;
+    if (prof) {
+      AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
+      h->prof_used += 2;
+    }
+    const bool direct = p.slabs == 1;  // one slab: its list is the answer, no merge launch
+    rc = dense_mfma_launch_topk(p, h->smat.as<float>(), (long)h->n, m, k, h->part.p,
+                                direct ? scores_dev + (size_t)q0 * k : nullptr,
+                                direct ? ids_dev + (size_t)q0 * k : nullptr, st);
+    if (rc) return rc;
+    if (!direct) {
+      size_t lds = (size_t)kWaves * p.cap * sizeof(C32) + kWaves * sizeof(int);
+      hipLaunchKernelGGL(dense_merge_kernel, dim3(m), dim3(256), lds, st, h->part.as<C32>(), p.slabs, m, k, p.cap,
+                         scores_dev + (size_t)q0 * k, (long long*)ids_dev + (size_t)q0 * k);
+      AMDR_HIP(hipGetLastError());
+    }
   }
   return AMDR_OK;
 }
 
 int run_search(amdr_dense* h, const float* Q_dev, int nq, int k, float* scores_dev, int64_t* ids_dev,
                hipStream_t st) {
+  if (nq >= kBatchedMin && h->n > 0 && dense_mfma_supported(h->d))
+    return run_search_batched(h, Q_dev, nq, k, scores_dev, ids_dev, st);
   ScanPlan p;
   make_plan(h->n, h->d, nq, k, &p);
   int rc = h->part.ensure(p.part_bytes);
@@ -306,12 +368,15 @@ int run_search(amdr_dense* h, const float* Q_dev, int nq, int k, float* scores_d
   C32* part = h->part.as<C32>();
   const bool prof = h->prof_on && (size_t)(h->prof_used + 2) <= h->prof_ev.size() && h->n > 0;
   if (prof) AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
+  const bool direct = h->n > 0 && p.grid_x == 1;
+  float* fs = direct ? scores_dev : nullptr;
+  int64_t* fi = direct ? ids_dev : nullptr;
   if (h->n > 0) {
     switch (p.nq_per_block) {
-      case 1: rc = launch_scan_ch<1>(p, h, Q_dev, nq, k, part, st); break;
-      case 2: rc = launch_scan_ch<2>(p, h, Q_dev, nq, k, part, st); break;
-      case 4: rc = launch_scan_ch<4>(p, h, Q_dev, nq, k, part, st); break;
-      default: rc = launch_scan_ch<8>(p, h, Q_dev, nq, k, part, st); break;
+      case 1: rc = launch_scan_ch<1>(p, h, Q_dev, nq, k, part, fs, fi, st); break;
+      case 2: rc = launch_scan_ch<2>(p, h, Q_dev, nq, k, part, fs, fi, st); break;
+      case 4: rc = launch_scan_ch<4>(p, h, Q_dev, nq, k, part, fs, fi, st); break;
+      default: rc = launch_scan_ch<8>(p, h, Q_dev, nq, k, part, fs, fi, st); break;
     }
     if (rc) return rc;
     AMDR_HIP(hipGetLastError());
@@ -320,6 +385,7 @@ int run_search(amdr_dense* h, const float* Q_dev, int nq, int k, float* scores_d
     AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
     h->prof_used += 2;
   }
+  if (direct) return AMDR_OK;
   int nparts = h->n > 0 ? p.grid_x : 0;
   size_t lds = (size_t)kWaves * p.cap * sizeof(C32) + kWaves * sizeof(int);
   hipLaunchKernelGGL(dense_merge_kernel, dim3(nq), dim3(256), lds, st, part, nparts, nq, k, p.cap, scores_dev,
@@ -434,6 +500,12 @@ int amdr_dense_reserve(amdr_dense_t* h, int32_t nq_max, int32_t k_max) {
   make_plan(h->n, h->d, nq_max, k_max, &p);
   int rc = h->part.ensure(p.part_bytes);
   if (rc) return rc;
+  if (nq_max >= kBatchedMin && h->n > 0 && dense_mfma_supported(h->d)) {
+    DenseMfmaPlan mp;
+    dense_mfma_plan((long)h->n, h->d, batched_chunk(h, nq_max), k_max, &mp);
+    if ((rc = h->smat.ensure(mp.s_bytes))) return rc;
+    if ((rc = h->part.ensure(mp.part_bytes))) return rc;
+  }
   if ((rc = h->qbuf.ensure((size_t)nq_max * h->d * sizeof(float)))) return rc;
   if ((rc = h->sbuf.ensure((size_t)nq_max * k_max * sizeof(float)))) return rc;
   return h->ibuf.ensure((size_t)nq_max * k_max * sizeof(int64_t));
@@ -521,6 +593,7 @@ int amdr_dense_destroy(amdr_dense_t* h) {
   }
   if (h->owns && h->X) (void)hipFree(h->X);
   h->part.release();
+  h->smat.release();
   h->qbuf.release();
   h->sbuf.release();
   h->ibuf.release();

@@ -55,10 +55,13 @@ __device__ __forceinline__ long long chan_uid(const ChanIn& c, int qi, int j) {
 __global__ __launch_bounds__(64) void fuse_kernel(amdr_fuse_params_t P, ChanIn c0, ChanIn c1, ChanIn c2, int max_out,
                                                   long long* __restrict__ out_ids, double* __restrict__ out_vals,
                                                   int* __restrict__ out_mask, int* __restrict__ out_count) {
-  __shared__ long long uid[kFuseMax];
-  __shared__ int pos[3][kFuseMax];
-  __shared__ double sc[kFuseMax];
-  __shared__ double tot[kFuseMax];
+  // dynamic LDS sized by max_out (<= kFuseMax): 36 bytes per candidate
+  extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+  long long* uid = reinterpret_cast<long long*>(fsm);
+  double* sc = reinterpret_cast<double*>(uid + max_out);
+  double* tot = sc + max_out;
+  int* pos0 = reinterpret_cast<int*>(tot + max_out);
+  int* pos[3] = {pos0, pos0 + max_out, pos0 + 2 * max_out};
   const int lane = threadIdx.x;
   const int qi = blockIdx.x;
   const ChanIn ch[3] = {c0, c1, c2};
@@ -374,7 +377,8 @@ int amdr_fuse_device(const amdr_fuse_params_t* p, int32_t nq, const int64_t* den
   ChanIn c0{(const long long*)dense_ids, dense_scores, (const long long*)dense_row2uid, kd, 0};
   ChanIn c1{(const long long*)bm25_ids, bm25_scores, (const long long*)bm25_row2uid, kb, 1};
   ChanIn c2{(const long long*)colbert_ids, colbert_scores, (const long long*)colbert_row2uid, kc, 0};
-  hipLaunchKernelGGL(fuse_kernel, dim3(nq), dim3(64), 0, (hipStream_t)stream, *p, c0, c1, c2, kd + kb + kc,
+  hipLaunchKernelGGL(fuse_kernel, dim3(nq), dim3(64), (size_t)(kd + kb + kc) * 36, (hipStream_t)stream, *p, c0, c1, c2,
+                     kd + kb + kc,
                      (long long*)out_ids, out_vals, out_mask, out_count);
   AMDR_HIP(hipGetLastError());
   return AMDR_OK;
@@ -425,7 +429,7 @@ int amdr_fuse(const amdr_fuse_params_t* p, int32_t nq, const int64_t* dense_ids,
   ChanIn c0{(const long long*)di.p, ds.p, nullptr, kd, 1};
   ChanIn c1{(const long long*)bi.p, bs.p, nullptr, kb, 1};
   ChanIn c2{(const long long*)ci.p, cs.p, nullptr, kc, 1};
-  hipLaunchKernelGGL(fuse_kernel, dim3(nq), dim3(64), 0, st, *p, c0, c1, c2, mo, (long long*)oi.p, (double*)ov.p,
+  hipLaunchKernelGGL(fuse_kernel, dim3(nq), dim3(64), (size_t)mo * 36, st, *p, c0, c1, c2, mo, (long long*)oi.p, (double*)ov.p,
                      (int*)om.p, (int*)oc.p);
   AMDR_HIP(hipGetLastError());
   AMDR_HIP(hipMemcpyAsync(out_ids, oi.p, (size_t)nq * mo * sizeof(int64_t), hipMemcpyDeviceToHost, st));

@@ -173,6 +173,14 @@ struct WaveTopK {
   __device__ inline void finalize(int lane) { compact(lane); }
 };
 
+template <int WAVES>
+__device__ __forceinline__ void block_sync() {
+  if (WAVES == 1)
+    wave_lds_fence();
+  else
+    __syncthreads();
+}
+
 // Merge the finalized lists of all waves of a block into wave 0's list.
 // Call with all threads; contains block barriers.  lists: [nwaves][stride]
 // where each wave's WaveTopK.buf == lists + wave*stride.
