@@ -28,20 +28,39 @@
 namespace amdr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));  // native vector: stays in registers (HIP's float4 struct did not)
 
 constexpr int kBW = 4;          // waves per block
 constexpr int kKC = 64;         // floats of every row per staged chunk (256 B = 16 slots of 16 B)
-constexpr int kStageBytes = 32 * kKC * 4;  // 8 KiB of LDS per wave: one 32-row x 64-float chunk
+constexpr int kStageBytes = 32 * kKC * 4;  // 8 KiB: one 32-row x 64-float chunk; each wave owns TWO (double buffer)
 
 // LDS image of a staged chunk: row r (0..31) at byte r*256, its logical 16-B slot s at
 // physical slot s ^ (r & 15), so that the 16 lanes of a ds_read_b128 group (16 different
 // rows, same logical slot) land on 16 different slots of the 256-B bank row.
 __device__ __forceinline__ int stage_off(int row, int slot) { return row * 256 + ((slot ^ (row & 15)) << 4); }
 
+// The three pipeline steps are macros, not functions: passing the register arrays by
+// reference made hipcc (ROCm 7.2) keep them in scratch memory.
+#define AMDR_STAGE_CHUNK(ST, G)                                                                   \
+  _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_)                                                \
+      *reinterpret_cast<v4f*>((ST) + stage_off(4 * p_ + lrow, lslot)) = G[p_];
+#define AMDR_READ_FRAGS(ST, C, FX, FQ)                                                            \
+  _Pragma("unroll") for (int m_ = 0; m_ < 8; ++m_) {                                              \
+    FX[m_] = *reinterpret_cast<const v4f*>((ST) + stage_off(i, h * 8 + m_));                   \
+    FQ[m_] = qsv[((C) * 16 + h * 8 + m_) * 32 + i];                                                \
+  }
+#define AMDR_MFMA_CHUNK(FX, FQ)                                                                   \
+  _Pragma("unroll") for (int m_ = 0; m_ < 8; ++m_) {                                              \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FQ[m_].x, FX[m_].x, acc, 0, 0, 0);                 \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FQ[m_].y, FX[m_].y, acc, 0, 0, 0);                 \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FQ[m_].z, FX[m_].z, acc, 0, 0, 0);                 \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FQ[m_].w, FX[m_].w, acc, 0, 0, 0);                 \
+  }
+
 // grid: (x = row slabs, y = 32-query tiles).
 // LDS: Q tile as [d/4][32] float4 (d*128 B) + kBW private 8-KiB chunk stages.
-template <int D8>  // D8 = d / 8
-__global__ __launch_bounds__(256) void dense_mfma_scores_kernel(const float* __restrict__ X, long n,
+template <int D8, int WAVES>  // D8 = d / 8; WAVES = 8 when the Q tile leaves room for 8 stages (d <= 768)
+__global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const float* __restrict__ X, long n,
                                                                  const float* __restrict__ Q, int nq,
                                                                  long rows_per_block,
                                                                  float* __restrict__ S /*[nq, n]*/) {
@@ -50,13 +69,14 @@ __global__ __launch_bounds__(256) void dense_mfma_scores_kernel(const float* __r
   constexpr int NCH = d / kKC;  // chunks per row: 6 / 12 / 16
   static_assert(d % kKC == 0, "dim must be a multiple of 64");
   float4* qs = reinterpret_cast<float4*>(smem);
+  const v4f* qsv = reinterpret_cast<const v4f*>(smem);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned char* stage = smem + (size_t)d * 128 + (size_t)wave * kStageBytes;
+  unsigned char* stage = smem + (size_t)d * 128 + (size_t)wave * 2 * kStageBytes;
   const int i = lane & 31, h = lane >> 5;
   const int q0 = blockIdx.y * 32;
 
   // ---- stage the query tile: qs[k4 * 32 + i] = Q[q0+i][4*k4 .. 4*k4+3], k4 in [0, d/4)
-  for (int k4 = threadIdx.x >> 5; k4 < d / 4; k4 += 8) {
+  for (int k4 = threadIdx.x >> 5; k4 < d / 4; k4 += WAVES * 2) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (q0 + i < nq) v = *reinterpret_cast<const float4*>(Q + (size_t)(q0 + i) * d + 4 * k4);
     qs[k4 * 32 + i] = v;
@@ -69,7 +89,7 @@ __global__ __launch_bounds__(256) void dense_mfma_scores_kernel(const float* __r
   // loader role of this lane inside a 1-KiB piece: 4 rows x 16 slots
   const int lrow = lane >> 4, lslot = lane & 15;
 
-  for (long r0 = row_lo + (long)wave * 32; r0 < row_hi; r0 += (long)kBW * 32) {
+  for (long r0 = row_lo + (long)wave * 32; r0 < row_hi; r0 += (long)WAVES * 32) {
     // global pointers of the 8 pieces (rows 4p + lrow), clamped at the slab end
     const float* gp[8];
 #pragma unroll
@@ -78,41 +98,54 @@ __global__ __launch_bounds__(256) void dense_mfma_scores_kernel(const float* __r
       if (r >= row_hi) r = row_hi - 1;
       gp[p] = X + (size_t)r * d + lslot * 4;
     }
-    float4 g0[8], g1[8];
+    // Software pipeline (explicitly named even/odd register sets so nothing is indexed at run time):
+    //   Ga/Gb   chunk c / c+1 as they arrive from HBM (two chunks always in flight)
+    //   stage   this wave's two LDS images (even / odd chunk, swizzled)
+    //   FXa/FQa, FXb/FQb   MFMA fragments of the even / odd chunk, read from LDS one chunk
+    //   AHEAD of their use so the dependent MFMA chain never waits on an LDS round trip.
+    v4f Ga[8], Gb[8], FXa[8], FQa[8], FXb[8], FQb[8];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) g0[p] = *reinterpret_cast<const float4*>(gp[p]);
+    for (int p = 0; p < 8; ++p) Ga[p] = *reinterpret_cast<const v4f*>(gp[p]);
     if (NCH > 1) {
 #pragma unroll
-      for (int p = 0; p < 8; ++p) g1[p] = *reinterpret_cast<const float4*>(gp[p] + kKC);
+      for (int p = 0; p < 8; ++p) Gb[p] = *reinterpret_cast<const v4f*>(gp[p] + kKC);
     }
+    AMDR_STAGE_CHUNK(stage, Ga)
+    if (NCH > 2) {
+#pragma unroll
+      for (int p = 0; p < 8; ++p) Ga[p] = *reinterpret_cast<const v4f*>(gp[p] + 2 * kKC);
+    }
+    wave_lds_fence();
+    AMDR_READ_FRAGS(stage, 0, FXa, FQa)
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      // registers -> this wave's LDS stage (swizzled), then refill the registers two chunks ahead
+    for (int c = 0; c < NCH; c += 2) {
+      // ---- even chunk c: prepare odd chunk c+1, compute on the even fragments
+      if (c + 1 < NCH) {
+        AMDR_STAGE_CHUNK(stage + kStageBytes, Gb)
+        if (c + 3 < NCH) {
 #pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        const float4 v = (c & 1) ? g1[p] : g0[p];
-        *reinterpret_cast<float4*>(stage + stage_off(4 * p + lrow, lslot)) = v;
-      }
-      if (c + 2 < NCH) {
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-          const float4 v = *reinterpret_cast<const float4*>(gp[p] + (c + 2) * kKC);
-          if (c & 1) g1[p] = v; else g0[p] = v;
+          for (int p = 0; p < 8; ++p) Gb[p] = *reinterpret_cast<const v4f*>(gp[p] + (c + 3) * kKC);
         }
+        wave_lds_fence();
+        AMDR_READ_FRAGS(stage + kStageBytes, c + 1, FXb, FQb)
       }
+      AMDR_MFMA_CHUNK(FXa, FQa)
       wave_lds_fence();
+      // ---- odd chunk c+1: prepare even chunk c+2, compute on the odd fragments
+      if (c + 1 < NCH) {
+        if (c + 2 < NCH) {
+          AMDR_STAGE_CHUNK(stage, Ga)
+          if (c + 4 < NCH) {
 #pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        const int sl = h * 8 + m;  // logical slot of this lane's half
-        const float4 xv = *reinterpret_cast<const float4*>(stage + stage_off(i, sl));
-        const float4 qv = qs[(c * 16 + sl) * 32 + i];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qv.x, xv.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qv.y, xv.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qv.z, xv.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qv.w, xv.w, acc, 0, 0, 0);
+            for (int p = 0; p < 8; ++p) Ga[p] = *reinterpret_cast<const v4f*>(gp[p] + (c + 4) * kKC);
+          }
+          wave_lds_fence();
+          AMDR_READ_FRAGS(stage, c + 2, FXa, FQa)
+        }
+        AMDR_MFMA_CHUNK(FXb, FQb)
+        wave_lds_fence();
       }
-      wave_lds_fence();
     }
     const long r = r0 + i;
     if (r < row_hi) {
@@ -170,20 +203,36 @@ __global__ __launch_bounds__(WAVES * 64) void scores_slab_topk_kernel(const floa
 bool dense_mfma_supported(int d) { return d == 384 || d == 768 || d == 1024; }
 
 // Plan shared by reserve and launch.
+static int scores_waves(int d) { return d <= 768 ? 4 : 2; }  // 2 x 8 KiB of stage per wave beside the Q tile
+
 void dense_mfma_plan(long n, int d, int nq, int k, DenseMfmaPlan* p) {
+  const int kBW = scores_waves(d);
   p->q_tiles = ceil_div(nq, 32);
   long tiles = (n + 31) / 32;
-  long want = 256L * 2;  // one block per CU is resident (Q tile fills most of the LDS); 2 rounds balance the tail
-  long gx = (want + p->q_tiles - 1) / p->q_tiles;
+  // Row slabs per query tile: one block per CU is resident (the Q tile fills most of the
+  // LDS), a block costs (tiles per wave) tile-times plus ~1/4 tile-time to stage Q, and
+  // blocks run in rounds of 256.  Pick the slab count with the smallest estimate.
   long gx_max = (tiles + kBW - 1) / kBW;  // at least one tile per wave
-  if (gx > gx_max) gx = gx_max;
-  if (gx < 1) gx = 1;
+  if (gx_max < 1) gx_max = 1;
+  long gx = 1;
+  double best = 1e300;
+  for (long g = 1; g <= gx_max && g <= 4096; ++g) {
+    long tpb = (tiles + g - 1) / g;
+    long per_wave = (tpb + kBW - 1) / kBW;
+    long rounds = ((long)p->q_tiles * g + 255) / 256;
+    double est = (double)rounds * ((double)per_wave + 0.25);
+    if (est < best - 1e-9) {
+      best = est;
+      gx = g;
+    }
+  }
   long tiles_per_block = (tiles + gx - 1) / gx;
   tiles_per_block = ((tiles_per_block + kBW - 1) / kBW) * kBW;
   p->rows_per_block = tiles_per_block * 32;
   p->grid_x = (int)((n + p->rows_per_block - 1) / p->rows_per_block);
   if (p->grid_x < 1) p->grid_x = 1;
-  p->lds_scores = (size_t)d * 32 * sizeof(float) + (size_t)kBW * kStageBytes;
+  p->lds_scores = (size_t)d * 32 * sizeof(float) + (size_t)kBW * 2 * kStageBytes;
+  p->waves = kBW;
   // top-k pass: slabs of >= 16 Ki rows, enough blocks to fill the chip
   long sl = (256L * 8 + nq - 1) / nq;
   long sl_max = (n + 16383) / 16384;
@@ -197,25 +246,26 @@ void dense_mfma_plan(long n, int d, int nq, int k, DenseMfmaPlan* p) {
   p->part_bytes = (size_t)p->slabs * nq * k * sizeof(C32);
 }
 
-template <int D8>
+template <int D8, int WAVES>
 static void launch_scores(const DenseMfmaPlan& p, const float* X, long n, const float* Q, int nq, float* S,
                           hipStream_t st) {
-  static bool attr_done = false;  // 96-128 KiB of dynamic LDS needs the opt-in once per kernel
+  static bool attr_done = false;  // 128-160 KiB of dynamic LDS needs the opt-in once per kernel
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)dense_mfma_scores_kernel<D8>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              D8 * 8 * 32 * (int)sizeof(float) + kBW * kStageBytes);
+    (void)hipFuncSetAttribute((const void*)dense_mfma_scores_kernel<D8, WAVES>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              D8 * 8 * 32 * (int)sizeof(float) + WAVES * 2 * kStageBytes);
     attr_done = true;
   }
-  hipLaunchKernelGGL((dense_mfma_scores_kernel<D8>), dim3(p.grid_x, p.q_tiles), dim3(256), p.lds_scores, st, X, n, Q,
-                     nq, p.rows_per_block, S);
+  hipLaunchKernelGGL((dense_mfma_scores_kernel<D8, WAVES>), dim3(p.grid_x, p.q_tiles), dim3(WAVES * 64),
+                     p.lds_scores, st, X, n, Q, nq, p.rows_per_block, S);
 }
 
 int dense_mfma_launch_scores(const DenseMfmaPlan& p, const float* X, long n, int d, const float* Q, int nq, float* S,
                              hipStream_t st) {
   switch (d) {
-    case 384: launch_scores<48>(p, X, n, Q, nq, S, st); break;
-    case 768: launch_scores<96>(p, X, n, Q, nq, S, st); break;
-    case 1024: launch_scores<128>(p, X, n, Q, nq, S, st); break;
+    case 384: launch_scores<48, 4>(p, X, n, Q, nq, S, st); break;
+    case 768: launch_scores<96, 4>(p, X, n, Q, nq, S, st); break;
+    case 1024: launch_scores<128, 2>(p, X, n, Q, nq, S, st); break;
     default: return fail(AMDR_EINVAL, "dense (batched): unsupported dim %d", d);
   }
   AMDR_HIP(hipGetLastError());
