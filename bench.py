@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="ucc_hybrid", choices=["ucc_hybrid", "synth10m"])
+    ap.add_argument("--workload", default="ucc_hybrid", choices=["ucc_hybrid", "ucc_colbert", "synth10m"])
     ap.add_argument("--shard", default="auto", choices=["auto", "queries", "corpus"])
     ap.add_argument("--repeat", type=int, default=8, help="ucc_hybrid: the query set is tiled this many times per step")
     ap.add_argument("--synth-rows", type=int, default=10_000_000)
@@ -61,7 +61,7 @@ def parse():
 
 
 # ---------------------------------------------------------------------------
-def build_ucc(device: int):
+def build_ucc(device: int, colbert: bool = False):
     """UCC-en corpus -> dense matrix (stand-in BGE embeddings), BM25 index, query set."""
     from legal_rag_amd import _native, text
     from legal_rag_amd.bm25_model import BM25Okapi
@@ -78,8 +78,15 @@ def build_ucc(device: int):
     Q = emb.encode_queries([q for q, _, _ in qs])
     q_tokens = [text.jieba_cut(q) for q, _, _ in qs]   # bm25_retriever.py:73 (not lower-cased)
     q_tid = [bm.term_ids(t) for t in q_tokens]
-    return dict(chunks=chunks, X=X, bm=bm, corpus_tokens=corpus_tokens, queries=qs, Q=Q, q_tokens=q_tokens,
-                q_tid=q_tid)
+    W = dict(chunks=chunks, X=X, bm=bm, corpus_tokens=corpus_tokens, queries=qs, Q=Q, q_tokens=q_tokens, q_tid=q_tid)
+    if colbert:
+        from legal_rag_amd.encoders import HashingTokenEmbedder
+        te = HashingTokenEmbedder()
+        mats = [te.encode_doc(c.text.strip()) for c in chunks]
+        W["D"] = np.concatenate(mats, axis=0)
+        W["doc_ptr"] = np.concatenate([[0], np.cumsum([m.shape[0] for m in mats])]).astype(np.int64)
+        W["Qtok"] = np.stack([te.encode_query(q.strip()) for q, _, _ in qs]).astype(np.float32)
+    return W
 
 
 def hybrid_recall(ids_top, counts, chunks, queries, k=10):
@@ -103,7 +110,12 @@ def oracle_pipeline(W, qi_list, k=10):
     for j, qi in enumerate(qi_list):
         d = [(int(i), float(s)) for s, i in zip(S[j], I[j]) if i >= 0]
         b = OB.search(ob, W["q_tokens"][qi], k)
-        fused = OF.fuse(d, b, [], {})
+        c = []
+        if "D" in W:
+            from oracle import maxsim as OM
+            cs, ci = OM.maxsim_topk(W["Qtok"][qi][None], W["D"], W["doc_ptr"], k)
+            c = [(int(i), float(np.float32(s))) for s, i in zip(cs[0], ci[0]) if i >= 0]
+        fused = OF.fuse(d, b, c, {})
         fused = [h for h in fused if h["score"] >= 0.2]
         out.append([h["id"] for h in fused[:k]])
     return out
@@ -208,6 +220,16 @@ def _hbm_scan_one(torch, _native, device, X, Q, n, d, B, steps, warmup, k):
     return out
 
 
+def with_colbert_tokens(result, scope):
+    """Annotate the colbert workload with the MaxSim work per step (no timing here)."""
+    W = scope.get("W")
+    if isinstance(W, dict) and "doc_ptr" in W and isinstance(result, dict) and "config" in result:
+        tokens = int(W["doc_ptr"][-1])
+        result["config"]["colbert_doc_tokens"] = tokens
+        result["config"]["maxsim_gflop_per_query"] = 2.0 * 32 * 128 * tokens / 1e9
+    return False
+
+
 # ---------------------------------------------------------------------------
 def main():
     a = parse()
@@ -217,9 +239,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs (single-GPU box): BENCH_FORCE_DEVICE=0 puts every rank on one card,
+    # BENCH_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks on one device)
+    if os.environ.get("BENCH_FORCE_DEVICE") is not None:
+        local = int(os.environ["BENCH_FORCE_DEVICE"])
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     if a.gpus != world:
         log(f"note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     if not torch.cuda.is_available():
@@ -239,11 +269,12 @@ def main():
         torch.cuda.synchronize()
 
     result = {}
-    if a.workload == "ucc_hybrid":
+    if a.workload in ("ucc_hybrid", "ucc_colbert"):
         K = 10
-        W = build_ucc(local)
+        with_colbert = a.workload == "ucc_colbert"
+        W = build_ucc(local, colbert=with_colbert)
         nq0 = len(W["queries"])
-        rep = max(1, a.repeat)
+        rep = 1 if with_colbert else max(1, a.repeat)
         shard = "queries" if a.shard == "auto" else a.shard
         n = W["X"].shape[0]
         if shard == "corpus" and world > 1:
@@ -264,7 +295,14 @@ def main():
                                     bm.k1, bm.b, device=local)
         else:
             bmi = bm.gpu(local)
-        eng = HybridEngine(dense, bmi, None, device=local)
+        msi = None
+        q_tok = None
+        if with_colbert:
+            if (lo, hi) != (0, n):
+                raise SystemExit("ucc_colbert: use --shard queries")
+            msi = _native.MaxSimIndex(W["D"], W["doc_ptr"], device=local)
+            q_tok = torch.from_numpy(np.tile(W["Qtok"], (rep, 1, 1))).to(device)
+        eng = HybridEngine(dense, bmi, msi, device=local)
         # ---- this rank's query batch, resident in HBM ----------------------
         Qh = np.tile(W["Q"], (rep, 1))
         tids = W["q_tid"] * rep
@@ -282,7 +320,7 @@ def main():
                 b = eng.bm25_topk(q_terms, q_ptr, K)
                 (ds, di), (bs, bi) = sharding.exchange_topk([d, b], lo)
                 return eng.fuse(params, nq, (ds, di), (bs, bi), None)
-            return eng.search_batch(params, K, q_emb=q_emb, q_terms=q_terms, q_ptr=q_ptr)
+            return eng.search_batch(params, K, q_emb=q_emb, q_terms=q_terms, q_ptr=q_ptr, q_tok=q_tok)
 
         for _ in range(a.warmup):
             step()
@@ -339,8 +377,10 @@ def main():
             "higher_is_better": True, "scaling": "weak" if shard == "queries" else "strong", "vs_baseline": None,
             "dtype": "f32 dense / f64 bm25+fusion", "data": "UCC-en law text (fixture) with deterministic stand-in "
             "embeddings (no BGE weights offline) and a seeded synthetic query set",
-            "config": {"workload": "UCC-en 591 chunks, dense(768-d FlatIP)+BM25 hybrid fusion top-10 "
-                                   "(BASELINE configs[1])", "queries_per_step_per_gpu": nq, "unique_queries": nq0,
+            "config": {"workload": ("UCC-en 591 chunks, dense(768-d FlatIP)+BM25+ColBERT MaxSim hybrid fusion top-10 "
+                                    "(BASELINE configs[2])" if with_colbert else
+                                    "UCC-en 591 chunks, dense(768-d FlatIP)+BM25 hybrid fusion top-10 "
+                                    "(BASELINE configs[1])"), "queries_per_step_per_gpu": nq, "unique_queries": nq0,
                        "top_k": K, "shard": shard, "fusion": "rrf_norm_blend w=0.6/0.4 alpha=0.5 rrf_k=60 "
                        "min_final=0.2"},
             "recall_at_10": rec, "latency_b1_us": lat_us, "roofline": roofline,
@@ -349,7 +389,7 @@ def main():
             # agreement@10 with the CPU oracle on identical inputs
             from oracle import bm25 as OB
             W["_oracle_bm25"] = OB.BM25Okapi(W["corpus_tokens"])
-            sample = list(range(0, nq0, max(1, nq0 // 256)))
+            sample = list(range(0, nq0, max(1, nq0 // (32 if with_colbert else 256))))
             exp = oracle_pipeline(W, sample, K)
             same = 0
             for j, qi in enumerate(sample):
@@ -414,6 +454,8 @@ def main():
         idx.close()
         del X
 
+    if with_colbert_tokens(result, locals()):
+        pass
     if rank == 0 and a.workload == "ucc_hybrid" and not a.no_hbm_scan:
         torch.cuda.empty_cache()
         try:

@@ -73,6 +73,10 @@ def check_dense(nat, X, Q, k):
     (100000, 768, 8, 10),    # multi-block slabs, 8 queries per pass
     (50000, 256, 33, 128),   # ragged query groups, deep k
     (3000, 64, 4, 256),      # max k
+    (5000, 384, 40, 80),     # batched fp32-MFMA path (nq >= 12), bge-small dim, ragged last query tile
+    (20000, 1024, 33, 256),  # batched path, d = 1024 (2-wave blocks), max k, multi-slab top-k + merge
+    (70000, 768, 64, 10),    # batched path, two full query tiles, several row slabs
+    (33, 768, 12, 50),       # batched path, k > n and a single partial row tile
 ])
 def test_dense_topk_matches_oracle(nat, n, d, nq, k):
     rng = np.random.default_rng(n * 31 + d + nq)
