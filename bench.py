@@ -204,7 +204,7 @@ def _hbm_scan_one(torch, _native, device, X, Q, n, d, B, steps, warmup, k):
     es, ei = OD.flatip_topk(X[:npre].cpu().numpy(), Qh, k)
     agree = float(np.mean(gi == ei))
     maxerr = float(np.max(np.abs(gs - es)))
-    batched = B >= 12  # 32-query-tile fp32-MFMA form: scores S[B, n] are written once and read once
+    batched = B >= 5  # 32-query-tile fp32-MFMA form: scores S[B, n] are written once and read once
     bytes_per_launch = float(n) * d * 4 + B * d * 4 + (float(n) * B * 4 if batched else B * k * 8)
     per_launch_ms = scan_ms / max(launches, 1)
     achieved = bytes_per_launch / (per_launch_ms * 1e-3) / 1e9

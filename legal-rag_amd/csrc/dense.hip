@@ -312,7 +312,7 @@ int launch_scan_ch(const ScanPlan& p, const amdr_dense* h, const float* Q, int n
 
 // Batches of >= kBatchedMin queries take the 32-query-tile MFMA path (dense_mfma.hip);
 // the score matrix workspace is bounded, so very large batches go in chunks of queries.
-constexpr int kBatchedMin = 12;
+constexpr int kBatchedMin = 5;  // measured: from 5 queries up one MFMA tile pass beats the 8-query GEMV pass
 constexpr size_t kScoreBytesMax = (size_t)4 << 30;
 
 int batched_chunk(const amdr_dense* h, int nq) {

@@ -200,10 +200,11 @@ __global__ __launch_bounds__(WAVES * 64) void scores_slab_topk_kernel(const floa
   }
 }
 
-bool dense_mfma_supported(int d) { return d == 384 || d == 768 || d == 1024; }
+bool dense_mfma_supported(int d) { return d >= 64 && d <= 1024 && d % 64 == 0; }
 
 // Plan shared by reserve and launch.
-static int scores_waves(int d) { return d <= 768 ? 4 : 2; }  // 2 x 8 KiB of stage per wave beside the Q tile
+// waves per block: each needs 2 x 8 KiB of stage beside the d*128-byte Q tile in 160 KiB of LDS
+static int scores_waves(int d) { return d <= 768 ? 4 : (d <= 832 ? 3 : 2); }
 
 void dense_mfma_plan(long n, int d, int nq, int k, DenseMfmaPlan* p) {
   const int kBW = scores_waves(d);
@@ -263,9 +264,11 @@ static void launch_scores(const DenseMfmaPlan& p, const float* X, long n, const 
 int dense_mfma_launch_scores(const DenseMfmaPlan& p, const float* X, long n, int d, const float* Q, int nq, float* S,
                              hipStream_t st) {
   switch (d) {
-    case 384: launch_scores<48, 4>(p, X, n, Q, nq, S, st); break;
-    case 768: launch_scores<96, 4>(p, X, n, Q, nq, S, st); break;
-    case 1024: launch_scores<128, 2>(p, X, n, Q, nq, S, st); break;
+#define AMDR_CASE(D, W) case D: launch_scores<D / 8, W>(p, X, n, Q, nq, S, st); break;
+    AMDR_CASE(64, 4) AMDR_CASE(128, 4) AMDR_CASE(192, 4) AMDR_CASE(256, 4) AMDR_CASE(320, 4) AMDR_CASE(384, 4)
+    AMDR_CASE(448, 4) AMDR_CASE(512, 4) AMDR_CASE(576, 4) AMDR_CASE(640, 4) AMDR_CASE(704, 4) AMDR_CASE(768, 4)
+    AMDR_CASE(832, 3) AMDR_CASE(896, 2) AMDR_CASE(960, 2) AMDR_CASE(1024, 2)
+#undef AMDR_CASE
     default: return fail(AMDR_EINVAL, "dense (batched): unsupported dim %d", d);
   }
   AMDR_HIP(hipGetLastError());

@@ -202,8 +202,17 @@ def test_search_batch_equals_single_queries(ucc_index):
     for q, got in zip(QUESTIONS, batch):
         exp = r.search(q, top_k=10)
         assert [h.chunk.id for h in got] == [h.chunk.id for h in exp]
-        assert [h.score for h in got] == [h.score for h in exp]
-        assert [h.score_breakdown for h in got] == [h.score_breakdown for h in exp]
+        # a batch of queries takes the 32-query-tile MFMA form of the dense scan, a single
+        # query the GEMV form: the fp32 dot products are summed in a different order, so dense
+        # scores (and everything derived from them) agree to rounding, not bit for bit
+        assert np.allclose([h.score for h in got], [h.score for h in exp], rtol=0, atol=2e-5)
+        for g, e in zip(got, exp):
+            gb, eb = g.score_breakdown, e.score_breakdown
+            assert gb["channel"] == eb["channel"] and gb["bm25_norm"] == eb["bm25_norm"]
+            for key in ("rrf_norm", "weighted_sum", "dense_norm", "colbert_norm"):
+                assert abs(gb[key] - eb[key]) <= 2e-5, key  # minmax divides by a small range
+            for ch in ("dense", "bm25", "colbert"):
+                assert abs(gb["channel_contrib"][ch] - eb["channel_contrib"][ch]) <= 2e-5
 
 
 def test_error_conventions(tmp_path):
