@@ -248,3 +248,58 @@ def test_reference_built_style_artifacts_load(tmp_path):
     from oracle import bm25 as OB
     ob = OB.BM25Okapi([OB.tokenize_en(c.text) for c in chunks])
     assert [(c.id, s) for c, s in got] == [(chunks[i].id, s) for i, s in OB.search(ob, ["seller", " ", "goods"], 5)]
+
+
+def test_incremental_add_and_hot_reload(tmp_path):
+    """§8f-3: IncrementalDenseBuilder / IncrementalBM25Builder semantics — id-dedup, append,
+    persisted artifacts, searches see the new rows, a second retriever reloads by mtime."""
+    import json
+    from legal_rag_amd.config import AppConfig
+    from legal_rag_amd.retrieval.bm25_retriever import BM25Retriever
+    from legal_rag_amd.retrieval.builders.bm25_builder import build_bm25_index
+    from legal_rag_amd.retrieval.builders.faiss_builder import build_faiss_index
+    from legal_rag_amd.retrieval.builders.incremental_bm25_builder import IncrementalBM25Builder
+    from legal_rag_amd.retrieval.builders.incremental_dense_builder import IncrementalDenseBuilder
+    from legal_rag_amd.retrieval.corpus_loader import load_chunks_from_dir
+    from legal_rag_amd.retrieval.dense_retriever import DenseRetriever
+    from legal_rag_amd import artifacts
+    cfg = AppConfig.for_data_dir(str(tmp_path), "en")
+    cfg.retrieval.encoder_backend = "hashing"
+    chunks = load_chunks_from_dir(str(GOLDEN / "corpus"), "law_en.jsonl")
+    base, extra = chunks[:60], chunks[55:90]  # 5 overlapping ids
+    build_faiss_index(cfg, base)
+    build_bm25_index(cfg, base)
+    dr = DenseRetriever(cfg)
+    target = extra[-1]
+    assert all(h.chunk.id != target.id for h in dr.search(target.text[:200], 5))
+    inc = tmp_path / "incoming.jsonl"
+    inc.write_text("".join(json.dumps(c.model_dump(), ensure_ascii=False) + "\n" for c in extra), encoding="utf-8")
+    assert IncrementalDenseBuilder(cfg).add_jsonl(inc) == 30
+    assert IncrementalDenseBuilder(cfg).add_jsonl(inc) == 0          # idempotent
+    X, _ = artifacts.read_faiss_index(cfg.retrieval.faiss_index_file)
+    meta = artifacts.read_faiss_meta(cfg.retrieval.faiss_meta_file)
+    assert X.shape[0] == len(meta) == 90 and [c.id for c in meta] == [c.id for c in chunks[:90]]
+    assert dr.search(target.text[:200], 3)[0].chunk.id == target.id  # same store object sees the new rows
+    br = BM25Retriever(cfg)
+    assert len(br.search("goods", 100)) == 60
+    assert IncrementalBM25Builder(cfg).add_jsonl(inc) == 30
+    assert len(br.search("goods", 100)) == 90                          # mtime-triggered reload
+    with pytest.raises(FileNotFoundError):
+        IncrementalDenseBuilder(cfg).add_jsonl(tmp_path / "missing.jsonl")
+
+
+def test_concurrent_searches_on_shared_singletons(ucc_index):
+    """The /retrieve service runs RETRIEVER.search from a thread pool on shared
+    singletons: results must not depend on interleaving."""
+    from concurrent.futures import ThreadPoolExecutor
+    from legal_rag_amd.retrieval.hybrid_retriever import HybridRetriever
+    cfg, _ = ucc_index
+    cfg2 = copy.deepcopy(cfg)
+    cfg2.retrieval.enable_rerank = False
+    r = HybridRetriever(cfg2)
+    expect = {q: [(h.chunk.id, h.score) for h in r.search(q, top_k=10)] for q in QUESTIONS}
+    work = QUESTIONS * 12
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        got = list(ex.map(lambda q: (q, [(h.chunk.id, h.score) for h in r.search(q, top_k=10)]), work))
+    for q, res in got:
+        assert res == expect[q]
