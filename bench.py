@@ -39,6 +39,16 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA == fp32 vector peak
 
 
+def pmc_traffic(key):
+    """HBM bytes per launch measured with rocprofv3 PMC in a separate run of this same
+    command (profiles/pmc_traffic.json); None if no measurement is on record."""
+    try:
+        rec = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text()).get(key)
+        return float(rec["bytes_per_launch"]) if rec else None
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def log(*a):
     if int(os.environ.get("RANK", "0")) == 0:
         print("[bench]", *a, file=sys.stderr, flush=True)
@@ -213,6 +223,8 @@ def _hbm_scan_one(torch, _native, device, X, Q, n, d, B, steps, warmup, k):
            "queries_per_s": B * steps / wall, "ms_per_scan_wall": wall / steps * 1e3,
            "scan_kernel_ms": per_launch_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
            "achieved_GBs": achieved, "peak_GBs": HBM_PEAK_GBS, "frac": achieved / HBM_PEAK_GBS,
+           "traffic": pmc_traffic(f"synth10m_b{B}/" + ("dense_mfma_scores_kernel" if batched else "dense_scan_topk_kernel"))
+           if (n == 10_000_000 and d == 768) else None,
            "f32_TFLOPs": 2.0 * n * d * B / (per_launch_ms * 1e-3) / 1e12,
            "oracle_prefix_rows": npre, "oracle_id_agreement": agree, "oracle_max_abs_err": maxerr}
     idx.close()
@@ -367,7 +379,10 @@ def main():
         achieved = flops_per_launch / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
         roofline = {"bound": "mfma", "kernel": "dense_mfma_scores_kernel (v_mfma_f32_32x32x2_f32, exact fp32)",
                     "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None, "launch_ms": per_launch_ms,
+                    "frac": achieved / F32_MFMA_PEAK_TFLOPS,
+                    "traffic": pmc_traffic("ucc_hybrid/dense_mfma_scores_kernel") if (not with_colbert and rep == 8
+                                                                                     and shard == "queries") else None,
+                    "launch_ms": per_launch_ms,
                     "algorithmic_flops": flops_per_launch,
                     "algorithmic_bytes": float(rows_local) * d * 4 + nq * d * 4 + float(rows_local) * nq * 4,
                     "note": "HBM-roofline evidence for the same channel on a 30.7 GB matrix is in hbm_scan"}
