@@ -129,6 +129,9 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
         }
         wave_lds_fence();
         AMDR_READ_FRAGS(stage + kStageBytes, c + 1, FXb, FQb)
+        // keep the fragment reads of chunk c+1 AHEAD of chunk c's MFMAs: left alone, hipcc
+        // sinks every ds_read next to its use and the chain stalls on LDS latency
+        __builtin_amdgcn_sched_barrier(0);
       }
       AMDR_MFMA_CHUNK(FXa, FQa)
       wave_lds_fence();
@@ -142,6 +145,7 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
           }
           wave_lds_fence();
           AMDR_READ_FRAGS(stage, c + 2, FXa, FQa)
+          __builtin_amdgcn_sched_barrier(0);
         }
         AMDR_MFMA_CHUNK(FXb, FQb)
         wave_lds_fence();
