@@ -171,6 +171,74 @@ class TransformersBGE:
         return self.encode([self.query_instruction + t for t in texts], batch_size, max_length)
 
 
+class TransformersColBERT:
+    """ColBERT token encoder for BERT-style checkpoints (colbert-ir/colbertv2.0 layout:
+    a BERT encoder + a bias-free `linear.weight` [dim, hidden]) on PyTorch-ROCm, following
+    the published ColBERT recipe: query = [CLS] [Q] tokens, padded to `query_maxlen` with
+    [MASK] (query augmentation; the pads are not attended to but their outputs are kept);
+    document = [CLS] [D] tokens truncated to `doc_maxlen`, punctuation tokens dropped;
+    every token vector L2-normalised.  [Q]/[D] are the tokenizer's [unused0]/[unused1].
+    Parity with colbert-ai is unpinned (the wheel and the weights are absent here)."""
+
+    def __init__(self, model_path: str, doc_maxlen: int = 220, query_maxlen: int = 32, device: Optional[str] = None):
+        import string
+
+        import torch
+        from safetensors import safe_open
+        from transformers import AutoModel, AutoTokenizer
+
+        self.torch = torch
+        self.device = torch.device(device or ("cuda" if torch.cuda.is_available() else "cpu"))
+        self.tok = AutoTokenizer.from_pretrained(model_path, local_files_only=True)
+        self.bert = AutoModel.from_pretrained(model_path, local_files_only=True).to(self.device).eval()
+        w = None
+        st = os.path.join(model_path, "model.safetensors")
+        if os.path.exists(st):
+            with safe_open(st, framework="pt") as f:
+                for key in f.keys():
+                    if key.endswith("linear.weight"):
+                        w = f.get_tensor(key)
+        lin = os.path.join(model_path, "colbert_linear.safetensors")
+        if w is None and os.path.exists(lin):
+            with safe_open(lin, framework="pt") as f:
+                w = f.get_tensor("linear.weight")
+        if w is None:
+            raise RuntimeError(f"no ColBERT projection (linear.weight) found under {model_path}")
+        self.linear = w.to(self.device).float()
+        self.dim = int(self.linear.shape[0])
+        self.doc_maxlen, self.query_maxlen = doc_maxlen, query_maxlen
+        self.q_id = self.tok.convert_tokens_to_ids("[unused0]")
+        self.d_id = self.tok.convert_tokens_to_ids("[unused1]")
+        self.skip = {self.tok.convert_tokens_to_ids(c) for c in string.punctuation}
+        self.skip.discard(self.tok.unk_token_id)
+
+    def _forward(self, ids, mask):
+        torch = self.torch
+        with torch.inference_mode():
+            h = self.bert(input_ids=ids, attention_mask=mask).last_hidden_state.float()
+            v = h @ self.linear.T
+            return torch.nn.functional.normalize(v, dim=-1)
+
+    def encode_query(self, text: str) -> np.ndarray:
+        torch = self.torch
+        body = self.tok(text, add_special_tokens=False)["input_ids"][: self.query_maxlen - 3]
+        ids = [self.tok.cls_token_id, self.q_id] + body + [self.tok.sep_token_id]
+        n_real = len(ids)
+        ids = ids + [self.tok.mask_token_id] * (self.query_maxlen - n_real)
+        mask = [1] * n_real + [0] * (self.query_maxlen - n_real)
+        out = self._forward(torch.tensor([ids], device=self.device), torch.tensor([mask], device=self.device))
+        return out[0].cpu().numpy().astype(np.float32)
+
+    def encode_doc(self, text: str) -> np.ndarray:
+        torch = self.torch
+        body = self.tok(text, add_special_tokens=False)["input_ids"][: self.doc_maxlen - 3]
+        ids = [self.tok.cls_token_id, self.d_id] + body + [self.tok.sep_token_id]
+        out = self._forward(torch.tensor([ids], device=self.device), torch.ones((1, len(ids)), dtype=torch.long,
+                                                                               device=self.device))[0]
+        keep = [j for j, t in enumerate(ids) if t not in self.skip]
+        return out[keep].cpu().numpy().astype(np.float32)
+
+
 _EMBEDDER_CACHE = {}
 
 

@@ -11,6 +11,7 @@ pid == row of colbert_meta.jsonl, exactly as the reference builder writes it.
 """
 from __future__ import annotations
 
+import os
 import threading
 from pathlib import Path
 from typing import ClassVar, Dict, List, Optional, Tuple
@@ -21,9 +22,22 @@ from .. import _native, artifacts, encoders
 from ..schemas import LawChunk
 
 
+_TOKEN_ENCODERS: Dict[Tuple[str, str, int], object] = {}
+
+
 def get_token_encoder(model_name: Optional[str], backend: str, doc_maxlen: int):
+    key = (str(model_name), backend, int(doc_maxlen))
+    if key in _TOKEN_ENCODERS:
+        return _TOKEN_ENCODERS[key]
     if backend == "hashing":
-        return encoders.HashingTokenEmbedder(doc_maxlen=doc_maxlen)
+        enc = encoders.HashingTokenEmbedder(doc_maxlen=doc_maxlen)
+    elif model_name and os.path.isdir(str(model_name)):
+        enc = encoders.TransformersColBERT(str(model_name), doc_maxlen=doc_maxlen)
+    else:
+        enc = None
+    if enc is not None:
+        _TOKEN_ENCODERS[key] = enc
+        return enc
     raise RuntimeError(
         f"ColBERT checkpoint '{model_name}' cannot be loaded offline (jina-colbert-v2 needs remote code and a "
         f"download); set cfg.retrieval.encoder_backend='hashing' for the deterministic stand-in token encoder.")

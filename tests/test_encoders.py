@@ -1,0 +1,115 @@
+"""Encoder plumbing (PyTorch forward passes of the path) on tiny randomly initialised
+checkpoints built on the fly — real BGE / ColBERT / cross-encoder weights are not
+available offline, so this checks the recipe (pooling, normalisation, instruction,
+padding, batching), not the numbers of a published model."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from legal_rag_amd import encoders
+from legal_rag_amd.retrieval import rerankers
+from legal_rag_amd.retrieval.colbert_retriever import get_token_encoder
+
+
+@pytest.fixture(scope="module")
+def tiny(tmp_path_factory):
+    from safetensors.torch import save_file
+    from tokenizers import Tokenizer, models, normalizers, pre_tokenizers, processors
+    from transformers import BertConfig, BertForSequenceClassification, BertModel, PreTrainedTokenizerFast
+    torch.manual_seed(0)
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", "[unused0]", "[unused1]", ".", ",", "?"] + \
+        [chr(c) for c in range(97, 123)] + ["the", "goods", "seller", "buyer", "warranty", "merchant", "of",
+                                            "为", "这", "个", "法", "律", "问", "题", "生", "成", "表", "示", "以", "用",
+                                            "于", "检", "索", "相", "关", "条", "文", "："]
+    out = {}
+    for name, cls, kw in (("bge", BertModel, {}), ("ce", BertForSequenceClassification, {"num_labels": 1})):
+        d = tmp_path_factory.mktemp(name)
+        wp = Tokenizer(models.WordPiece({w: i for i, w in enumerate(vocab)}, unk_token="[UNK]"))
+        wp.normalizer = normalizers.BertNormalizer(lowercase=True)
+        wp.pre_tokenizer = pre_tokenizers.BertPreTokenizer()
+        wp.post_processor = processors.TemplateProcessing(
+            single="[CLS] $A [SEP]", pair="[CLS] $A [SEP] $B:1 [SEP]:1", special_tokens=[("[CLS]", 2), ("[SEP]", 3)])
+        tok = PreTrainedTokenizerFast(tokenizer_object=wp, unk_token="[UNK]", pad_token="[PAD]", cls_token="[CLS]",
+                                      sep_token="[SEP]", mask_token="[MASK]")
+        cfg = BertConfig(vocab_size=len(vocab), hidden_size=32, num_hidden_layers=2, num_attention_heads=2,
+                         intermediate_size=64, max_position_embeddings=80, **kw)
+        m = cls(cfg).eval()
+        m.save_pretrained(str(d))
+        tok.save_pretrained(str(d))
+        out[name] = str(d)
+    save_file({"linear.weight": torch.randn(16, 32)}, os.path.join(out["bge"], "colbert_linear.safetensors"))
+    return out
+
+
+def test_bge_recipe_cls_pool_normalise_instruction(tiny):
+    from transformers import AutoModel, AutoTokenizer
+    enc = encoders.TransformersBGE(tiny["bge"], device="cpu")
+    texts = ["the seller goods", "buyer", "warranty of the merchant goods the goods", ""]
+    E = enc.encode(texts, batch_size=2)
+    assert E.shape == (4, 32) and E.dtype == np.float32
+    assert np.allclose(np.linalg.norm(E, axis=1), 1.0, atol=1e-5)
+    tok = AutoTokenizer.from_pretrained(tiny["bge"])
+    model = AutoModel.from_pretrained(tiny["bge"]).eval()
+    with torch.inference_mode():
+        for i, t in enumerate(texts):  # CLS pooling, one text at a time (no padding effects)
+            h = model(**tok([t], return_tensors="pt")).last_hidden_state[:, 0]
+            ref = torch.nn.functional.normalize(h, dim=-1)[0].numpy()
+            assert np.allclose(E[i], ref, atol=1e-5), i
+    q = enc.encode_queries(["the goods"])
+    assert np.allclose(q, enc.encode([encoders.QUERY_INSTRUCTION + "the goods"]), atol=1e-6)
+    assert not np.allclose(q, enc.encode(["the goods"]), atol=1e-3)
+    assert enc.encode([]).shape == (0, 32) and enc.encode("buyer").shape == (32,)
+    assert enc.hidden_size == 32
+
+
+def test_get_embedder_resolution(tiny):
+    assert isinstance(encoders.get_embedder(tiny["bge"], backend="auto"), encoders.TransformersBGE)
+    assert isinstance(encoders.get_embedder("BAAI/bge-base-en-v1.5", backend="hashing"), encoders.HashingEmbedder)
+    with pytest.raises(RuntimeError):
+        encoders.get_embedder("BAAI/bge-base-en-v1.5", backend="auto")  # not a local dir, no network: loud
+
+
+def test_hashing_standins_are_deterministic_unit_vectors():
+    a, b = encoders.HashingEmbedder(64), encoders.HashingEmbedder(64)
+    x = a.encode(["Sale of goods", "sale of GOODS", "other words"])
+    assert np.array_equal(x, b.encode(["Sale of goods", "sale of GOODS", "other words"]))
+    assert np.allclose(np.linalg.norm(x, axis=1), 1) and np.array_equal(x[0], x[1]) and not np.allclose(x[0], x[2])
+    t = encoders.HashingTokenEmbedder()
+    q, d = t.encode_query("sale of goods"), t.encode_doc("goods " * 400)
+    assert q.shape == (32, 128) and d.shape == (220, 128) and np.allclose(np.linalg.norm(q, axis=1), 1, atol=1e-6)
+    s = encoders.HashingCrossScorer().score_batch("sale goods", ["goods for sale", "unrelated text"])
+    assert s[0] > s[1] and all(0 < v < 1.01 for v in s)
+
+
+def test_colbert_token_encoder_recipe(tiny):
+    enc = get_token_encoder(tiny["bge"], "auto", 24)
+    assert isinstance(enc, encoders.TransformersColBERT) and enc.dim == 16
+    q = enc.encode_query("the seller?")
+    assert q.shape == (32, 16) and np.allclose(np.linalg.norm(q, axis=1), 1, atol=1e-5)
+    d = enc.encode_doc("the goods, the seller. warranty")
+    # [CLS] [D] the goods the seller warranty [SEP] with "," and "." dropped
+    assert d.shape == (8, 16) and np.allclose(np.linalg.norm(d, axis=1), 1, atol=1e-5)
+    long = enc.encode_doc("goods " * 100)
+    assert long.shape[0] == 24
+    with pytest.raises(RuntimeError):
+        get_token_encoder("jinaai/jina-colbert-v2", "auto", 220)
+
+
+def test_cross_encoder_reranker_sigmoid_of_logit(tiny):
+    from transformers import AutoModelForSequenceClassification, AutoTokenizer
+    ce = rerankers.CrossEncoderReranker(model_name=tiny["ce"], device="cpu", batch_size=2)
+    docs = ["the goods", "warranty of the merchant", "buyer"]
+    got = ce.score_batch("seller goods", docs)
+    tok = AutoTokenizer.from_pretrained(tiny["ce"])
+    model = AutoModelForSequenceClassification.from_pretrained(tiny["ce"]).eval()
+    with torch.inference_mode():
+        for g, d in zip(got, docs):
+            logit = model(**tok(["seller goods"], [d], return_tensors="pt")).logits[0, 0]
+            assert abs(g - float(torch.sigmoid(logit))) < 1e-5
+    assert ce.score("seller goods", "buyer") == pytest.approx(got[2], abs=1e-6)
+    with pytest.raises(RuntimeError):
+        rerankers.CrossEncoderReranker(model_name="BAAI/bge-reranker-v2-m3")
+    f = rerankers.RerankerFactory(llm=None, cross_model=tiny["ce"])
+    assert f.create(5) is f.create(7)  # class-level cache, like the reference
