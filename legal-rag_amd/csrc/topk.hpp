@@ -96,6 +96,8 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// Sorts buf[0 .. cap) descending; cap must be a power of two (callers pass the smallest
+// power of two covering the staged candidates, not the whole buffer).
 template <class C>
 __device__ inline void wave_bitonic_sort_desc(C* buf, int cap, int lane) {
   for (int size = 2; size <= cap; size <<= 1) {
@@ -134,8 +136,11 @@ struct WaveTopK {
   }
 
   __device__ inline void compact(int lane) {
-    for (int i = cnt + lane; i < cap; i += 64) buf[i] = C::pad();
-    wave_bitonic_sort_desc(buf, cap, lane);
+    // sort only the smallest power of two that covers the staged candidates
+    int m = 2;
+    while (m < cnt) m <<= 1;
+    for (int i = cnt + lane; i < m; i += 64) buf[i] = C::pad();
+    wave_bitonic_sort_desc(buf, m, lane);
     if (cnt > k) cnt = k;
     if (cnt == k) thr = buf[k - 1];
   }
