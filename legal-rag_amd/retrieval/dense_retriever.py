@@ -1,6 +1,11 @@
-"""Dense channel (legalrag/retrieval/dense_retriever.py:14-60): embed the query,
-exact inner-product top-k on the GPU, wrap RetrievalHits.  Ranks are the 1-based
-positions in the index result with gaps kept when an id is dropped (:46-48)."""
+"""Dense channel (counterpart of legalrag/retrieval/dense_retriever.py:14-60).
+
+`search(query, top_k)`: reload the store if its files changed, embed the query
+(with the retrieval instruction), run the exact inner-product top-k on the GPU
+and wrap the rows as RetrievalHits.  As in the reference, `rank` is the 1-based
+position in the index result — positions whose id is out of range (the -1
+padding when k > ntotal) are skipped and leave a gap — and `semantic_score`
+repeats the score."""
 from __future__ import annotations
 
 from dataclasses import dataclass
@@ -16,21 +21,18 @@ class DenseRetriever:
     store: Optional[VectorStore] = None
 
     def __post_init__(self) -> None:
-        if self.store is None:
-            self.store = VectorStore.from_config(self.cfg)
+        self.store = self.store or VectorStore.from_config(self.cfg)
 
     def search(self, query: str, top_k: int) -> List[RetrievalHit]:
-        assert self.store is not None
-        self.store.load()
-        k = max(1, int(top_k))
-        q_vec = self.store._embed([query], is_query=True)
-        scores, idxs = self.store.index.search(q_vec, k)
-        scores = scores[0].tolist()
-        idxs = idxs[0].tolist()
-        hits: List[RetrievalHit] = []
-        for rank, (i, s) in enumerate(zip(idxs, scores), start=1):
-            if i < 0 or i >= len(self.store.chunks):
-                continue
-            hits.append(RetrievalHit(chunk=self.store.chunks[i], score=float(s), rank=rank, source="retriever",
-                                     semantic_score=float(s)))
-        return hits
+        store = self.store
+        store.load()
+        depth = max(1, int(top_k))
+        scores, rows = store.index.search(store._embed([query], is_query=True), depth)
+        n_chunks = len(store.chunks)
+        out: List[RetrievalHit] = []
+        for position, (row, score) in enumerate(zip(rows[0].tolist(), scores[0].tolist()), start=1):
+            if 0 <= row < n_chunks:
+                s = float(score)
+                out.append(RetrievalHit(chunk=store.chunks[row], score=s, rank=position, source="retriever",
+                                        semantic_score=s))
+        return out

@@ -143,3 +143,32 @@ def test_synthetic_queries_are_deterministic(ucc):
     a = evaluation.synthetic_queries(ucc, seed=0)
     assert a == evaluation.synthetic_queries(ucc, seed=0) and len(a) == 1168
     assert a[0] == ("Short Titles", "1-101", "title")
+
+
+def test_colbert_from_config_does_not_deadlock(tmp_path, monkeypatch):
+    """from_config() builds the instance under the registry lock and the instance fills the
+    searcher cache under the same lock: it must be re-entrant (regression: this hung a GPU run)."""
+    import threading
+
+    from legal_rag_amd import _native
+    from legal_rag_amd.retrieval.builders.colbert_builder import build_colbert_index
+    from legal_rag_amd.retrieval.colbert_retriever import ColBERTRetriever
+
+    class FakeMaxSim:
+        def __init__(self, D, doc_ptr, device=0):
+            self.n_docs = len(doc_ptr) - 1
+
+    monkeypatch.setattr(_native, "MaxSimIndex", FakeMaxSim)
+    cfg = AppConfig.for_data_dir(str(tmp_path), "en")
+    cfg.retrieval.encoder_backend = "hashing"
+    chunks = load_chunks_from_dir(str(GOLDEN / "corpus"), "law_en.jsonl")[:5]
+    out = build_colbert_index(cfg, chunks)
+    assert (out / "amdr_tokens.npz").exists()
+    box = {}
+    t = threading.Thread(target=lambda: box.setdefault("r", ColBERTRetriever.from_config(cfg)), daemon=True)
+    t.start()
+    t.join(20)
+    assert not t.is_alive(), "ColBERTRetriever.from_config deadlocked"
+    r = box["r"]
+    assert r.enabled and r._searcher.n_docs == 5 and ColBERTRetriever.from_config(cfg) is r
+    assert r.search("   ", 3) == []
