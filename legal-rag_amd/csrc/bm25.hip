@@ -10,13 +10,14 @@
 // them.  fp64, compiled with -ffp-contract=off: bit-identical scores.  The
 // slab is then ranked in place (score desc, ties -> lower doc id, zero-score
 // docs included) with the wave-level selector of topk.hpp.
-// Algorithmic bytes per query: sum_t df(t)*8 (postings) + touched doc_len*4.
+// Algorithmic bytes per query: sum_t df(t)*12 (posting doc id + precomputed fp64 factor).
 #include "common.hpp"
 #include "topk.hpp"
 
 #include <cfloat>
 #include <mutex>
 #include <new>
+#include <vector>
 
 namespace amdr {
 
@@ -39,9 +40,8 @@ __device__ __forceinline__ long lower_bound_i32(const int* __restrict__ a, long 
 // directly and the merge launch is skipped.
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void bm25_score_topk_kernel(
-    const long long* __restrict__ term_ptr, const int* __restrict__ post_doc, const int* __restrict__ post_tf,
-    const double* __restrict__ idf, const int* __restrict__ doc_len, long n_terms, long n_docs, double avgdl,
-    double k1, double k1p1, double one_minus_b, double b, const int* __restrict__ q_terms,
+    const long long* __restrict__ term_ptr, const int* __restrict__ post_doc, const double* __restrict__ post_w,
+    const double* __restrict__ idf, long n_terms, long n_docs, const int* __restrict__ q_terms,
     const long long* __restrict__ q_ptr, int nq, int k, int cap, int slab,
     double* __restrict__ scores_out /* nullable [nq, n_docs] */, C64* __restrict__ part /* nullable [nslabs][nq][k] */,
     double* __restrict__ fin_scores /* nullable [nq,k]: single slab */, long long* __restrict__ fin_ids) {
@@ -71,11 +71,9 @@ __global__ __launch_bounds__(WAVES * 64) void bm25_score_topk_kernel(
     for (long p = ps + tid; p < p1; p += NT) {
       const int doc = post_doc[p];
       if (doc >= hi) break;
-      const double qf = (double)post_tf[p];
-      const double dl = (double)doc_len[doc];
-      // rank_bm25: idf * (q_freq * (k1 + 1) / (q_freq + k1 * (1 - b + b * doc_len / avgdl)))
-      const double denom = qf + k1 * (one_minus_b + b * dl / avgdl);
-      sc[doc - lo] += w * (qf * k1p1 / denom);
+      // rank_bm25: idf * (q_freq * (k1 + 1) / (q_freq + k1 * (1 - b + b * doc_len / avgdl)));
+      // the parenthesis depends only on (tf, doc) and is evaluated once at index creation
+      sc[doc - lo] += w * post_w[p];
     }
     block_sync<WAVES>();
   }
@@ -153,9 +151,8 @@ struct amdr_bm25 {
   double avgdl = 0, k1 = 1.5, b = 0.75;
   long long* term_ptr = nullptr;
   int* post_doc = nullptr;
-  int* post_tf = nullptr;
+  double* post_w = nullptr;  // tf*(k1+1) / (tf + k1*(1 - b + b*len/avgdl)) per posting, fp64
   double* idf = nullptr;
-  int* doc_len = nullptr;
   hipStream_t stream = nullptr;
   std::mutex mu;
   DevBuf part, qterms, qptr, sbuf, ibuf, full;
@@ -195,12 +192,12 @@ int bm_run(amdr_bm25* h, const int* q_terms_dev, const long long* q_ptr_dev, int
   if (direct) part = nullptr;
   if (p.waves == 1)
     hipLaunchKernelGGL(bm25_score_topk_kernel<1>, dim3(p.nslabs, nq), dim3(64), p.lds, st, h->term_ptr, h->post_doc,
-                       h->post_tf, h->idf, h->doc_len, (long)h->n_terms, (long)h->n_docs, h->avgdl, h->k1, h->k1 + 1,
-                       1 - h->b, h->b, q_terms_dev, q_ptr_dev, nq, k, p.cap, p.slab, full_dev, part, fs, fi);
+                       h->post_w, h->idf, (long)h->n_terms, (long)h->n_docs, q_terms_dev, q_ptr_dev, nq, k, p.cap,
+                       p.slab, full_dev, part, fs, fi);
   else
     hipLaunchKernelGGL(bm25_score_topk_kernel<kBmWaves>, dim3(p.nslabs, nq), dim3(256), p.lds, st, h->term_ptr,
-                       h->post_doc, h->post_tf, h->idf, h->doc_len, (long)h->n_terms, (long)h->n_docs, h->avgdl, h->k1,
-                       h->k1 + 1, 1 - h->b, h->b, q_terms_dev, q_ptr_dev, nq, k, p.cap, p.slab, full_dev, part, fs, fi);
+                       h->post_doc, h->post_w, h->idf, (long)h->n_terms, (long)h->n_docs, q_terms_dev, q_ptr_dev, nq,
+                       k, p.cap, p.slab, full_dev, part, fs, fi);
   AMDR_HIP(hipGetLastError());
   if (scores_dev && !direct) {
     size_t lds = (size_t)kBmWaves * p.cap * sizeof(C64) + kBmWaves * sizeof(int);
@@ -254,11 +251,23 @@ int amdr_bm25_create(const int64_t* term_ptr, const int32_t* post_doc, const int
   h->avgdl = avgdl;
   h->k1 = k1;
   h->b = b;
+  // Per-posting factor of rank_bm25's expression, operand for operand in numpy's order
+  // (this translation unit is built with -ffp-contract=off; IEEE fp64 mul/add/div are
+  // correctly rounded on the host as on the device, so the value is the one numpy computes).
+  std::vector<double> pw((size_t)nnz);
+  {
+    const double k1p1 = k1 + 1, one_minus_b = 1 - b;
+    for (int64_t p = 0; p < nnz; ++p) {
+      const double qf = (double)post_tf[p];
+      const double dl = (double)doc_len[post_doc[p]];
+      const double denom = qf + k1 * (one_minus_b + b * dl / avgdl);
+      pw[(size_t)p] = qf * k1p1 / denom;
+    }
+  }
   rc = upload(&h->term_ptr, (const long long*)term_ptr, (size_t)n_terms + 1);
   if (!rc) rc = upload(&h->post_doc, post_doc, (size_t)nnz);
-  if (!rc) rc = upload(&h->post_tf, post_tf, (size_t)nnz);
+  if (!rc) rc = upload(&h->post_w, pw.data(), (size_t)nnz);
   if (!rc) rc = upload(&h->idf, idf, (size_t)n_terms);
-  if (!rc) rc = upload(&h->doc_len, doc_len, (size_t)n_docs);
   if (!rc && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
     rc = fail(AMDR_EHIP, "bm25_create: stream");
   if (rc) {
@@ -370,9 +379,8 @@ int amdr_bm25_destroy(amdr_bm25_t* h) {
   }
   if (h->term_ptr) (void)hipFree(h->term_ptr);
   if (h->post_doc) (void)hipFree(h->post_doc);
-  if (h->post_tf) (void)hipFree(h->post_tf);
+  if (h->post_w) (void)hipFree(h->post_w);
   if (h->idf) (void)hipFree(h->idf);
-  if (h->doc_len) (void)hipFree(h->doc_len);
   h->part.release();
   h->qterms.release();
   h->qptr.release();
