@@ -47,8 +47,14 @@ __device__ __forceinline__ int stage_off(int row, int slot) { return row * 256 +
 #define AMDR_READ_FRAGS(ST, C, FX, FQ)                                                            \
   _Pragma("unroll") for (int m_ = 0; m_ < 8; ++m_) {                                              \
     FX[m_] = *reinterpret_cast<const v4f*>((ST) + stage_off(i, h * 8 + m_));                   \
-    FQ[m_] = qsv[((C) * 16 + h * 8 + m_) * 32 + i];                                                \
+    FQ[m_] = qsv[i * (d / 4) + ((((C) * 16 + h * 8 + m_)) ^ (i & 15))];                               \
   }
+#if defined(AMDR_ABLATE) && AMDR_ABLATE == 1  // timing-only build: matrix pipe removed, operands kept live
+#define AMDR_MFMA_CHUNK(FX, FQ)                                                                   \
+  _Pragma("unroll") for (int m_ = 0; m_ < 8; ++m_) {                                              \
+    acc[m_] += FQ[m_].x * FX[m_].x + FQ[m_].y * FX[m_].y + FQ[m_].z * FX[m_].z + FQ[m_].w * FX[m_].w; \
+  }
+#else
 #define AMDR_MFMA_CHUNK(FX, FQ)                                                                   \
   _Pragma("unroll") for (int m_ = 0; m_ < 8; ++m_) {                                              \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FQ[m_].x, FX[m_].x, acc, 0, 0, 0);                 \
@@ -56,9 +62,36 @@ __device__ __forceinline__ int stage_off(int row, int slot) { return row * 256 +
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FQ[m_].z, FX[m_].z, acc, 0, 0, 0);                 \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FQ[m_].w, FX[m_].w, acc, 0, 0, 0);                 \
   }
+#endif
+// Issue pattern of one half step (sched_group_barrier masks: 0x008 MFMA, 0x020 VMEM read,
+// 0x100 DS read, 0x200 DS write): 8 x {MFMA, ds_write, global_load}, 16 x {MFMA, ds_read}, 8 x MFMA.
+// Measured A/B in one process on one device (rule 24): leaving this region to hipcc's own
+// scheduler is 2-7 % FASTER than the pinned pattern (B=8 scan 5.27 vs 5.67 ms, B=32 6.16 vs
+// 6.25-6.8 ms, UCC step kernel 122 vs 127 us), so the pattern is opt-in only.
+#if !defined(AMDR_PIN_SCHEDULE)
+#define AMDR_INTERLEAVE()
+#else
+#define AMDR_INTERLEAVE()                                                                         \
+  _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                              \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                            \
+    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                            \
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                            \
+  }                                                                                               \
+  _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) {                                             \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                            \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                            \
+  }                                                                                               \
+  __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+#endif
+
+#if defined(AMDR_ABLATE) && AMDR_ABLATE == 2  // timing-only build: no X traffic (registers filled from an address hash)
+#define AMDR_LDX(PTR) ([&] { v4f z_; z_.x = z_.y = z_.z = z_.w = (float)(((size_t)(PTR)) & 1023) * 1e-3f; return z_; }())
+#else
+#define AMDR_LDX(PTR) (*reinterpret_cast<const v4f*>(PTR))
+#endif
 
 // grid: (x = row slabs, y = 32-query tiles).
-// LDS: Q tile as [d/4][32] float4 (d*128 B) + kBW private 8-KiB chunk stages.
+// LDS: Q tile row-major [32][d/4] float4, slots XOR-swizzled per row (d*128 B) + kBW private 8-KiB chunk stages.
 template <int D8, int WAVES>  // D8 = d / 8; WAVES = 8 when the Q tile leaves room for 8 stages (d <= 768)
 __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const float* __restrict__ X, long n,
                                                                  const float* __restrict__ Q, int nq,
@@ -68,18 +101,44 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
   constexpr int d = D8 * 8;
   constexpr int NCH = d / kKC;  // chunks per row: 6 / 12 / 16
   static_assert(d % kKC == 0, "dim must be a multiple of 64");
-  float4* qs = reinterpret_cast<float4*>(smem);
   const v4f* qsv = reinterpret_cast<const v4f*>(smem);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned char* stage = smem + (size_t)d * 128 + (size_t)wave * 2 * kStageBytes;
   const int i = lane & 31, h = lane >> 5;
   const int q0 = blockIdx.y * 32;
 
-  // ---- stage the query tile: qs[k4 * 32 + i] = Q[q0+i][4*k4 .. 4*k4+3], k4 in [0, d/4)
-  for (int k4 = threadIdx.x >> 5; k4 < d / 4; k4 += WAVES * 2) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (q0 + i < nq) v = *reinterpret_cast<const float4*>(Q + (size_t)(q0 + i) * d + 4 * k4);
-    qs[k4 * 32 + i] = v;
+  // ---- stage the query tile, row-major with a per-row XOR swizzle of the 16-byte slots:
+  //   qs[i * d/4 + (k4 ^ (i & 15))] = Q[q0+i][4*k4 .. 4*k4+3]
+  // Global reads are fully coalesced (a wave reads 1 KiB of one query row per instruction);
+  // both the staging writes (8 consecutive slots of one row per ds_write_b128 lane group) and
+  // the fragment reads (same logical slot of 16 different rows per ds_read_b128 lane group;
+  // row stride d*4 is a multiple of the 256-B bank row) are conflict-free.
+  // Loads are issued in batches of 16 per thread BEFORE any of them is consumed: one load per
+  // loop trip serialises 24+ L2 round trips (measured: ~14 us of a 25-us block at UCC-en size).
+  {
+    constexpr int NT = WAVES * 64, TOTAL = 32 * (d / 4), PER = (TOTAL + NT - 1) / NT, BATCH = 16;
+#pragma unroll
+    for (int j0 = 0; j0 < PER; j0 += BATCH) {
+      v4f tmp[BATCH];
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
+        if (j0 + j < PER) {
+          const int idx = threadIdx.x + (j0 + j) * NT;
+          const int qi_ = idx / (d / 4), k4 = idx - qi_ * (d / 4);
+          v4f z = {0.f, 0.f, 0.f, 0.f};
+          tmp[j] = (idx < TOTAL && q0 + qi_ < nq) ? *reinterpret_cast<const v4f*>(Q + (size_t)(q0 + qi_) * d + 4 * k4)
+                                                  : z;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
+        if (j0 + j < PER) {
+          const int idx = threadIdx.x + (j0 + j) * NT;
+          const int qi_ = idx / (d / 4), k4 = idx - qi_ * (d / 4);
+          if (idx < TOTAL) reinterpret_cast<v4f*>(smem)[qi_ * (d / 4) + (k4 ^ (qi_ & 15))] = tmp[j];
+        }
+      }
+    }
   }
   __syncthreads();
 
@@ -105,49 +164,50 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
     //   AHEAD of their use so the dependent MFMA chain never waits on an LDS round trip.
     v4f Ga[8], Gb[8], FXa[8], FQa[8], FXb[8], FQb[8];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) Ga[p] = *reinterpret_cast<const v4f*>(gp[p]);
+    for (int p = 0; p < 8; ++p) Ga[p] = AMDR_LDX(gp[p]);
     if (NCH > 1) {
 #pragma unroll
-      for (int p = 0; p < 8; ++p) Gb[p] = *reinterpret_cast<const v4f*>(gp[p] + kKC);
+      for (int p = 0; p < 8; ++p) Gb[p] = AMDR_LDX(gp[p] + kKC);
     }
     AMDR_STAGE_CHUNK(stage, Ga)
     if (NCH > 2) {
 #pragma unroll
-      for (int p = 0; p < 8; ++p) Ga[p] = *reinterpret_cast<const v4f*>(gp[p] + 2 * kKC);
+      for (int p = 0; p < 8; ++p) Ga[p] = AMDR_LDX(gp[p] + 2 * kKC);
     }
     wave_lds_fence();
     AMDR_READ_FRAGS(stage, 0, FXa, FQa)
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < NCH; c += 2) {
-      // ---- even chunk c: prepare odd chunk c+1, compute on the even fragments
+      // Each half step is ONE scheduling region: the 32 dependent MFMAs of the chunk in the
+      // chain, and in their shadow the staging of the next chunk (8 ds_write), the refill of
+      // its registers from HBM (8 loads) and its fragment reads (16 ds_read).  The LDS unit
+      // serves a wave's operations in order and the compiler keeps the may-alias write->read
+      // order on `stage`, so no fence is needed inside the region.
+      // ---- even chunk c in the chain; odd chunk c+1 prepared
       if (c + 1 < NCH) {
         AMDR_STAGE_CHUNK(stage + kStageBytes, Gb)
         if (c + 3 < NCH) {
 #pragma unroll
-          for (int p = 0; p < 8; ++p) Gb[p] = *reinterpret_cast<const v4f*>(gp[p] + (c + 3) * kKC);
+          for (int p = 0; p < 8; ++p) Gb[p] = AMDR_LDX(gp[p] + (c + 3) * kKC);
         }
-        wave_lds_fence();
         AMDR_READ_FRAGS(stage + kStageBytes, c + 1, FXb, FQb)
-        // keep the fragment reads of chunk c+1 AHEAD of chunk c's MFMAs: left alone, hipcc
-        // sinks every ds_read next to its use and the chain stalls on LDS latency
-        __builtin_amdgcn_sched_barrier(0);
       }
       AMDR_MFMA_CHUNK(FXa, FQa)
+      AMDR_INTERLEAVE()
       wave_lds_fence();
-      // ---- odd chunk c+1: prepare even chunk c+2, compute on the odd fragments
+      // ---- odd chunk c+1 in the chain; even chunk c+2 prepared
       if (c + 1 < NCH) {
         if (c + 2 < NCH) {
           AMDR_STAGE_CHUNK(stage, Ga)
           if (c + 4 < NCH) {
 #pragma unroll
-            for (int p = 0; p < 8; ++p) Ga[p] = *reinterpret_cast<const v4f*>(gp[p] + (c + 4) * kKC);
+            for (int p = 0; p < 8; ++p) Ga[p] = AMDR_LDX(gp[p] + (c + 4) * kKC);
           }
-          wave_lds_fence();
           AMDR_READ_FRAGS(stage, c + 2, FXa, FQa)
-          __builtin_amdgcn_sched_barrier(0);
         }
         AMDR_MFMA_CHUNK(FXb, FQb)
+        AMDR_INTERLEAVE()
         wave_lds_fence();
       }
     }
