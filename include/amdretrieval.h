@@ -13,6 +13,9 @@
  * "_device" variants take DEVICE pointers and a hipStream_t passed as void*
  * (0 = the null stream); they enqueue work and return without synchronising,
  * and are graph-capturable once amdr_*_reserve() has sized the workspace.
+ * A handle owns ONE workspace: "_device" calls on the same handle must be
+ * ordered with respect to each other (same stream, or events between streams);
+ * the host-pointer variants are always safe to call concurrently.
  * Plain variants take HOST pointers, run on the handle's private stream and
  * return after the results are in the host buffers.
  */
