@@ -172,3 +172,39 @@ def test_colbert_from_config_does_not_deadlock(tmp_path, monkeypatch):
     r = box["r"]
     assert r.enabled and r._searcher.n_docs == 5 and ColBERTRetriever.from_config(cfg) is r
     assert r.search("   ", 3) == []
+
+
+def test_llm_rerankers_and_factory_choice():
+    import asyncio
+
+    class FakeLLM:
+        def __init__(self):
+            self.calls = 0
+
+        def chat(self, messages, tag=None):
+            self.calls += 1
+            doc = messages[1]["content"]
+            if "alpha" in doc:
+                return '{"score": 0.9, "reason": "direct"}'
+            if "beta" in doc:
+                return "I would say 0.25 maybe"
+            if "gamma" in doc:
+                return '{"score": 7}'
+            return "no idea"
+
+    llm = FakeLLM()
+    r = rerankers.LLMReranker(llm=llm)
+    assert r.score_batch("q", ["alpha text", "beta text", "gamma", "delta"]) == [0.9, 0.25, 1.0, 0.0]
+    assert "Candidate provision:" in rerankers.build_llm_rerank_prompt("q", "d")
+    c = rerankers.CachedLLMReranker(llm=llm)
+    n0 = llm.calls
+    assert c.score("q", "alpha") == 0.9 and c.score("q", "alpha") == 0.9 and llm.calls == n0 + 1
+    f = rerankers.RerankerFactory(llm=llm, cross_model="missing-model", llm_threshold=30)
+    assert isinstance(f.create(10), rerankers.CachedLLMReranker)      # llm given and top_k <= threshold
+    with pytest.raises(RuntimeError):
+        f.create(31)                                                   # falls to the cross-encoder: not local -> loud
+    a = rerankers.AsyncCachedLLMReranker(llm=llm, max_concurrency=2)
+    got = asyncio.run(a.score_batch("q", ["alpha", "beta", "alpha"]))
+    assert got == [0.9, 0.25, 0.9]
+    long_q = "x" * 1000
+    assert len(r._call_llm(long_q, "alpha")) > 0
