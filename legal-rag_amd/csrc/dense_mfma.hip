@@ -10,12 +10,12 @@
 // rate as the vector ALU, but the 32x32 accumulate needs no cross-lane traffic.
 //   A (32 queries x 2): lane (i = l&31, h = l>>5) <- Q[q0+i][k]   (LDS, staged once per block)
 //   B (2 x 32 rows)   : lane (j = l&31, h)        <- X[r0+j][k]   (HBM -> registers -> LDS -> registers)
-// X is fetched with fully coalesced 16-B/lane loads (4 rows x 256 B per wave
+// X is fetched with fully coalesced 16-B/lane loads (8 rows x 128 B per wave
 // instruction, each byte of X read from HBM exactly once), parked in a wave-private,
-// XOR-swizzled 8-KiB LDS stage and read back row-per-lane as the MFMA wants it; two
-// chunks (16 KiB per wave) are always in flight.  The k order inside a chunk is
-// permuted (lane half h takes slots 8h..8h+7); A and B use the same permutation,
-// which a dot product cannot see.  C[query][row] comes
+// XOR-swizzled, double-buffered 4-KiB LDS stage and read back row-per-lane as the MFMA
+// wants it; two 32-float chunks per wave (64 KiB per CU with 8 waves) are always in flight.
+// The k order inside a chunk is permuted (lane half h takes slots 4h..4h+3); A and B use
+// the same permutation, which a dot product cannot see.  C[query][row] comes
 // back with the row on the lane, so each accumulator register is stored as two
 // 128-byte segments of the score matrix S[query][row].  Top-k is a second,
 // slab-parallel pass over S (+8 % traffic at d = 768: 128 B written and read per
@@ -31,32 +31,36 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));  // native vector: stays in registers (HIP's float4 struct did not)
 
 constexpr int kBW = 4;          // waves per block
-constexpr int kKC = 64;         // floats of every row per staged chunk (256 B = 16 slots of 16 B)
-constexpr int kStageBytes = 32 * kKC * 4;  // 8 KiB: one 32-row x 64-float chunk; each wave owns TWO (double buffer)
+constexpr int kKC = 32;         // floats of every row per staged chunk (128 B = 8 slots of 16 B)
+constexpr int kStageBytes = 32 * kKC * 4;  // 4 KiB: one 32-row x 32-float chunk; each wave owns TWO (double buffer)
+constexpr int kPieces = kStageBytes / 1024;  // 1-KiB wave loads per chunk (4): 8 rows x 128 B each
+constexpr int kFr = kKC / 8;                  // float4 fragments per lane and chunk (4): its half of the 8 slots
 
-// LDS image of a staged chunk: row r (0..31) at byte r*256, its logical 16-B slot s at
-// physical slot s ^ (r & 15), so that the 16 lanes of a ds_read_b128 group (16 different
-// rows, same logical slot) land on 16 different slots of the 256-B bank row.
-__device__ __forceinline__ int stage_off(int row, int slot) { return row * 256 + ((slot ^ (row & 15)) << 4); }
+// LDS image of a staged chunk: row r (0..31) at byte r*128 — two rows share one 256-B bank
+// row — with its logical 16-B slot s (0..7) at physical slot s ^ ((r >> 1) & 7).  A
+// ds_read_b128 lane group covers 16 different rows at the same logical slot: 8 distinct
+// physical slots x the 2 halves of the bank row = conflict-free; a ds_write_b128 lane group
+// (8 contiguous lanes) writes the 8 slots of one row.
+__device__ __forceinline__ int stage_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
 
 // The three pipeline steps are macros, not functions: passing the register arrays by
 // reference made hipcc (ROCm 7.2) keep them in scratch memory.
 #define AMDR_STAGE_CHUNK(ST, G)                                                                   \
-  _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_)                                                \
-      *reinterpret_cast<v4f*>((ST) + stage_off(4 * p_ + lrow, lslot)) = G[p_];
+  _Pragma("unroll") for (int p_ = 0; p_ < kPieces; ++p_)                                          \
+      *reinterpret_cast<v4f*>((ST) + stage_off(8 * p_ + lrow, lslot)) = G[p_];
 #define AMDR_READ_FRAGS(ST, C, FX, FQ)                                                            \
-  _Pragma("unroll") for (int m_ = 0; m_ < 8; ++m_) {                                              \
-    FX[m_] = *reinterpret_cast<const v4f*>((ST) + stage_off(i, h * 8 + m_));                   \
-    FQ[m_] = qsv[i * (d / 4) + ((((C) * 16 + h * 8 + m_)) ^ (i & 15))];                               \
+  _Pragma("unroll") for (int m_ = 0; m_ < kFr; ++m_) {                                            \
+    FX[m_] = *reinterpret_cast<const v4f*>((ST) + stage_off(i, h * kFr + m_));                    \
+    FQ[m_] = qsv[i * (d / 4) + ((((C) * 2 * kFr + h * kFr + m_)) ^ (i & 15))];                    \
   }
 #if defined(AMDR_ABLATE) && AMDR_ABLATE == 1  // timing-only build: matrix pipe removed, operands kept live
 #define AMDR_MFMA_CHUNK(FX, FQ)                                                                   \
-  _Pragma("unroll") for (int m_ = 0; m_ < 8; ++m_) {                                              \
+  _Pragma("unroll") for (int m_ = 0; m_ < kFr; ++m_) {                                            \
     acc[m_] += FQ[m_].x * FX[m_].x + FQ[m_].y * FX[m_].y + FQ[m_].z * FX[m_].z + FQ[m_].w * FX[m_].w; \
   }
 #else
 #define AMDR_MFMA_CHUNK(FX, FQ)                                                                   \
-  _Pragma("unroll") for (int m_ = 0; m_ < 8; ++m_) {                                              \
+  _Pragma("unroll") for (int m_ = 0; m_ < kFr; ++m_) {                                            \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FQ[m_].x, FX[m_].x, acc, 0, 0, 0);                 \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FQ[m_].y, FX[m_].y, acc, 0, 0, 0);                 \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FQ[m_].z, FX[m_].z, acc, 0, 0, 0);                 \
@@ -91,7 +95,7 @@ __device__ __forceinline__ int stage_off(int row, int slot) { return row * 256 +
 #endif
 
 // grid: (x = row slabs, y = 32-query tiles).
-// LDS: Q tile row-major [32][d/4] float4, slots XOR-swizzled per row (d*128 B) + kBW private 8-KiB chunk stages.
+// LDS: Q tile row-major [32][d/4] float4, slots XOR-swizzled per row (d*128 B) + per wave two private 4-KiB chunk stages.
 template <int D8, int WAVES>  // D8 = d / 8; WAVES = 8 when the Q tile leaves room for 8 stages (d <= 768)
 __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const float* __restrict__ X, long n,
                                                                  const float* __restrict__ Q, int nq,
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
                                                                  float* __restrict__ S /*[nq, n]*/) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int d = D8 * 8;
-  constexpr int NCH = d / kKC;  // chunks per row: 6 / 12 / 16
+  constexpr int NCH = d / kKC;  // chunks per row: 12 / 24 / 32 (always even: d % 64 == 0)
   static_assert(d % kKC == 0, "dim must be a multiple of 64");
   const v4f* qsv = reinterpret_cast<const v4f*>(smem);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -145,15 +149,15 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
   const long row_lo = (long)blockIdx.x * rows_per_block;
   long row_hi = row_lo + rows_per_block;
   if (row_hi > n) row_hi = n;
-  // loader role of this lane inside a 1-KiB piece: 4 rows x 16 slots
-  const int lrow = lane >> 4, lslot = lane & 15;
+  // loader role of this lane inside a 1-KiB piece: 8 rows x 8 slots
+  const int lrow = lane >> 3, lslot = lane & 7;
 
   for (long r0 = row_lo + (long)wave * 32; r0 < row_hi; r0 += (long)WAVES * 32) {
     // global pointers of the 8 pieces (rows 4p + lrow), clamped at the slab end
-    const float* gp[8];
+    const float* gp[kPieces];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      long r = r0 + 4 * p + lrow;
+    for (int p = 0; p < kPieces; ++p) {
+      long r = r0 + 8 * p + lrow;
       if (r >= row_hi) r = row_hi - 1;
       gp[p] = X + (size_t)r * d + lslot * 4;
     }
@@ -162,17 +166,17 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
     //   stage   this wave's two LDS images (even / odd chunk, swizzled)
     //   FXa/FQa, FXb/FQb   MFMA fragments of the even / odd chunk, read from LDS one chunk
     //   AHEAD of their use so the dependent MFMA chain never waits on an LDS round trip.
-    v4f Ga[8], Gb[8], FXa[8], FQa[8], FXb[8], FQb[8];
+    v4f Ga[kPieces], Gb[kPieces], FXa[kFr], FQa[kFr], FXb[kFr], FQb[kFr];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) Ga[p] = AMDR_LDX(gp[p]);
+    for (int p = 0; p < kPieces; ++p) Ga[p] = AMDR_LDX(gp[p]);
     if (NCH > 1) {
 #pragma unroll
-      for (int p = 0; p < 8; ++p) Gb[p] = AMDR_LDX(gp[p] + kKC);
+      for (int p = 0; p < kPieces; ++p) Gb[p] = AMDR_LDX(gp[p] + kKC);
     }
     AMDR_STAGE_CHUNK(stage, Ga)
     if (NCH > 2) {
 #pragma unroll
-      for (int p = 0; p < 8; ++p) Ga[p] = AMDR_LDX(gp[p] + 2 * kKC);
+      for (int p = 0; p < kPieces; ++p) Ga[p] = AMDR_LDX(gp[p] + 2 * kKC);
     }
     wave_lds_fence();
     AMDR_READ_FRAGS(stage, 0, FXa, FQa)
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
         AMDR_STAGE_CHUNK(stage + kStageBytes, Gb)
         if (c + 3 < NCH) {
 #pragma unroll
-          for (int p = 0; p < 8; ++p) Gb[p] = AMDR_LDX(gp[p] + (c + 3) * kKC);
+          for (int p = 0; p < kPieces; ++p) Gb[p] = AMDR_LDX(gp[p] + (c + 3) * kKC);
         }
         AMDR_READ_FRAGS(stage + kStageBytes, c + 1, FXb, FQb)
       }
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
           AMDR_STAGE_CHUNK(stage, Ga)
           if (c + 4 < NCH) {
 #pragma unroll
-            for (int p = 0; p < 8; ++p) Ga[p] = AMDR_LDX(gp[p] + (c + 4) * kKC);
+            for (int p = 0; p < kPieces; ++p) Ga[p] = AMDR_LDX(gp[p] + (c + 4) * kKC);
           }
           AMDR_READ_FRAGS(stage, c + 2, FXa, FQa)
         }
@@ -267,8 +271,11 @@ __global__ __launch_bounds__(WAVES * 64) void scores_slab_topk_kernel(const floa
 bool dense_mfma_supported(int d) { return d >= 64 && d <= 1024 && d % 64 == 0; }
 
 // Plan shared by reserve and launch.
-// waves per block: each needs 2 x 8 KiB of stage beside the d*128-byte Q tile in 160 KiB of LDS
-static int scores_waves(int d) { return d <= 768 ? 4 : (d <= 832 ? 3 : 2); }
+// waves per block: each needs 2 x 4 KiB of stage beside the d*128-byte Q tile in 160 KiB of LDS
+static int scores_waves(int d) {
+  int w = (int)((160 * 1024 - (long)d * 128) / (2 * kStageBytes));
+  return w > 8 ? 8 : w;  // d <= 768: 8 waves (two per SIMD); d = 1024: 4
+}
 
 void dense_mfma_plan(long n, int d, int nq, int k, DenseMfmaPlan* p) {
   const int kBW = scores_waves(d);
@@ -329,9 +336,9 @@ int dense_mfma_launch_scores(const DenseMfmaPlan& p, const float* X, long n, int
                              hipStream_t st) {
   switch (d) {
 #define AMDR_CASE(D, W) case D: launch_scores<D / 8, W>(p, X, n, Q, nq, S, st); break;
-    AMDR_CASE(64, 4) AMDR_CASE(128, 4) AMDR_CASE(192, 4) AMDR_CASE(256, 4) AMDR_CASE(320, 4) AMDR_CASE(384, 4)
-    AMDR_CASE(448, 4) AMDR_CASE(512, 4) AMDR_CASE(576, 4) AMDR_CASE(640, 4) AMDR_CASE(704, 4) AMDR_CASE(768, 4)
-    AMDR_CASE(832, 3) AMDR_CASE(896, 2) AMDR_CASE(960, 2) AMDR_CASE(1024, 2)
+    AMDR_CASE(64, 8) AMDR_CASE(128, 8) AMDR_CASE(192, 8) AMDR_CASE(256, 8) AMDR_CASE(320, 8) AMDR_CASE(384, 8)
+    AMDR_CASE(448, 8) AMDR_CASE(512, 8) AMDR_CASE(576, 8) AMDR_CASE(640, 8) AMDR_CASE(704, 8) AMDR_CASE(768, 8)
+    AMDR_CASE(832, 7) AMDR_CASE(896, 6) AMDR_CASE(960, 5) AMDR_CASE(1024, 4)
 #undef AMDR_CASE
     default: return fail(AMDR_EINVAL, "dense (batched): unsupported dim %d", d);
   }
