@@ -85,6 +85,20 @@ def test_dense_topk_matches_oracle(nat, n, d, nq, k):
     check_dense(nat, X, Q, k)
 
 
+def test_dense_fuzz_shapes(nat):
+    """Seeded sweep over awkward shapes: both dense forms (GEMV for < 5 queries or d % 64 != 0,
+    32-query MFMA tiles otherwise), partial row tiles, partial query tiles, k around n."""
+    rng = np.random.default_rng(20261004)
+    for it in range(40):
+        d = int(rng.choice([4, 36, 64, 100, 128, 192, 320, 384, 512, 704, 768, 832, 1024]))
+        n = int(rng.choice([1, 2, 31, 32, 33, 63, 65, 257, 591, 1023, 1260, 2500, 6000]))
+        nq = int(rng.choice([1, 2, 4, 5, 7, 12, 31, 32, 33, 70]))
+        k = int(rng.choice([1, 3, 10, 64, 80, 129, 256]))
+        X = unit_rows(rng, n, d)
+        Q = unit_rows(rng, nq, d)
+        check_dense(nat, X, Q, k)
+
+
 def test_dense_golden_fixture(nat):
     """Seeded fixture of SURVEY.md §8c(3): X[4096,768], Q[16,768], rng(0)."""
     g = np.load(str(__import__("conftest").GOLDEN / "dense_flatip_golden.npz"))
@@ -354,3 +368,65 @@ def test_fuse_batched_equals_single(nat):
         i1, v1, m1, c1 = nat.fuse(p, 1, (di[q:q + 1], ds[q:q + 1]), (bi[q:q + 1], bs[q:q + 1]), None)
         assert np.array_equal(I[q], i1[0]) and np.array_equal(V[q], v1[0]) and np.array_equal(M[q], m1[0])
         assert Cn[q] == c1[0]
+
+
+def test_fuse_fuzz_vs_oracle(nat):
+    """Random channel lists (ragged depths up to 256, overlapping ids, random knobs, all four
+    methods) through amdr_fuse vs the reference-pinned oracle: bit-exact, incl. the filter count."""
+    from oracle import fusion as F
+    rng = np.random.default_rng(77)
+    methods = ["rrf_norm_blend", "rrf", "wrrf", "weighted_sum"]
+    for it in range(120):
+        pool = int(rng.choice([3, 12, 40, 300, 900]))
+        ks = [int(rng.choice([0, 1, 5, 10, 80, 256])) for _ in range(3)]
+        if sum(ks) == 0:
+            ks[0] = 4
+        chans = []
+        for c, kk in enumerate(ks):
+            kk = min(kk, pool)
+            ids = rng.choice(pool, size=kk, replace=False).astype(np.int64)
+            sc = np.sort(rng.uniform(-1, 40, size=kk))[::-1].copy()
+            if c != 1:
+                sc = sc.astype(np.float32).astype(np.float64)
+            if it % 7 == 0 and kk > 2:
+                sc[:] = sc[0]  # flat channel -> minmax degenerates to zeros
+            chans.append((ids, sc))
+        kn = {"fusion_method": methods[it % 4], "rrf_k": int(rng.choice([1, 10, 60])), "rrf_alpha": float(rng.uniform(0, 1)),
+              "dense_weight": float(rng.uniform(0, 1)), "bm25_weight": float(rng.uniform(0, 1)),
+              "colbert_weight": float(rng.uniform(0, 1))}
+        min_final = float(rng.choice([-np.inf, 0.0, 0.2, 0.5]))
+        args = [(i[None, :], s[None, :]) if len(i) else None for i, s in chans]
+        ids, vals, mask, count = nat.fuse(_params(nat, kn, min_final), 1, *args)
+        exp = F.fuse(*[[(int(i), float(s)) for i, s in zip(ci, cs)] for ci, cs in chans], kn)
+        got = [(int(ids[0, r]), float(vals[0, r, 0])) for r in range(len(exp))]
+        # equal scores may be permuted only inside exact-tie groups, and the oracle and the kernel
+        # both break ties by first appearance -> identical order expected
+        assert got == [(h["id"], h["score"]) for h in exp], (it, kn)
+        assert count[0] == sum(1 for h in exp if h["score"] >= min_final)
+        for r, h in enumerate(exp):
+            sb = h["breakdown"]
+            assert vals[0, r, 1] == sb["rrf_norm"] and vals[0, r, 2] == sb["weighted_sum"]
+            assert [vals[0, r, 3], vals[0, r, 4], vals[0, r, 5]] == [sb["dense_norm"], sb["bm25_norm"], sb["colbert_norm"]]
+            assert [vals[0, r, 6 + c] for c in range(3)] == [sb["channel_contrib"][n] for n in ("dense", "bm25", "colbert")]
+
+
+def test_bm25_fuzz_vs_oracle(nat):
+    from oracle import bm25 as OB
+    rng = np.random.default_rng(4242)
+    for it in range(12):
+        n_docs = int(rng.choice([1, 2, 63, 64, 65, 1000, 1025, 4096, 4097, 10000]))
+        vocab = int(rng.choice([3, 50, 800]))
+        docs, words = toy_corpus(rng, n_docs, vocab, int(rng.choice([1, 12, 90])))
+        ob, csr, gi = bm25_pair(nat, docs)
+        k = int(rng.choice([1, 10, 100, 256]))
+        queries = [[words[j] for j in rng.integers(0, vocab, size=int(rng.integers(0, 9)))] + (["?"] if q % 2 else [])
+                   for q in range(5)]
+        tid = [[csr["vocab"].get(t, -1) for t in q] for q in queries]
+        s, i = gi.search(tid, k)
+        full = gi.get_scores(tid)
+        for qn, q in enumerate(queries):
+            assert np.array_equal(full[qn], ob.get_scores(q))
+            exp = OB.search(ob, q, k)
+            kk = min(k, n_docs)
+            assert i[qn, :kk].tolist() == [e[0] for e in exp] and s[qn, :kk].tolist() == [e[1] for e in exp]
+        gi.close()
