@@ -68,6 +68,12 @@ int amdr_dense_search(amdr_dense_t* h, const float* Q_host, int32_t nq, int32_t 
                       float* scores_host, int64_t* ids_host);
 int amdr_dense_search_device(amdr_dense_t* h, const float* Q_dev, int32_t nq, int32_t k,
                              float* scores_dev, int64_t* ids_dev, void* stream);
+/* scores of an explicit candidate list: out[q, j] = <Q[q], X[rows[q, j]]>, -FLT_MAX for
+ * rows outside [0, n).  Building block for GraphRetriever's candidate rescoring
+ * (legalrag/retrieval/graph_retriever.py:177-191 re-embeds up to graph_limit=800 candidate
+ * texts per query and takes cosines; the embeddings are already resident here). */
+int amdr_dense_score_rows(amdr_dense_t* h, const float* Q_host, int32_t nq, const int64_t* rows_host, int32_t m,
+                          float* scores_host);
 /* copy rows [row0, row0+nrows) back to the host (used by parity tests to run
  * the oracle on exactly the matrix that is resident in HBM) */
 int amdr_dense_read_rows(const amdr_dense_t* h, int64_t row0, int64_t nrows, float* out_host);

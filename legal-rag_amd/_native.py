@@ -29,7 +29,7 @@ FV = dict(score=0, rrf_norm=1, weighted_sum=2, dense_norm=3, bm25_norm=4, colber
 EXPORTS = (
     "amdr_last_error", "amdr_version", "amdr_device_count", "amdr_device_name",
     "amdr_dense_create", "amdr_dense_create_from_device", "amdr_dense_add", "amdr_dense_ntotal", "amdr_dense_dim",
-    "amdr_dense_reserve", "amdr_dense_search", "amdr_dense_search_device", "amdr_dense_read_rows",
+    "amdr_dense_reserve", "amdr_dense_search", "amdr_dense_search_device", "amdr_dense_read_rows", "amdr_dense_score_rows",
     "amdr_dense_profile_begin", "amdr_dense_profile_end", "amdr_dense_destroy",
     "amdr_bm25_create", "amdr_bm25_ndocs", "amdr_bm25_reserve", "amdr_bm25_search", "amdr_bm25_search_device",
     "amdr_bm25_scores", "amdr_bm25_destroy",
@@ -179,6 +179,17 @@ class DenseIndex:
     def search_device(self, q_ptr: int, nq: int, k: int, scores_ptr: int, ids_ptr: int, stream: int = 0) -> None:
         _check(load().amdr_dense_search_device(self._h, _vp(q_ptr), C.c_int32(nq), C.c_int32(k), _vp(scores_ptr),
                                                _vp(ids_ptr), _vp(stream)), "amdr_dense_search_device")
+
+    def score_rows(self, Q: np.ndarray, rows: np.ndarray) -> np.ndarray:
+        """out[q, j] = <Q[q], X[rows[q, j]]> (rows outside [0, n) -> -FLT_MAX)."""
+        Q = _c(Q, np.float32)
+        if Q.ndim == 1:
+            Q = Q[None, :]
+        rows = _c(rows, np.int64).reshape(Q.shape[0], -1)
+        out = np.empty(rows.shape, dtype=np.float32)
+        _check(load().amdr_dense_score_rows(self._h, _p(Q, C.c_float), C.c_int32(Q.shape[0]), _p(rows, C.c_int64),
+                                            C.c_int32(rows.shape[1]), _p(out, C.c_float)), "amdr_dense_score_rows")
+        return out
 
     def read_rows(self, row0: int, nrows: int) -> np.ndarray:
         out = np.empty((nrows, self.d), dtype=np.float32)

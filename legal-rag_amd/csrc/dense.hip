@@ -131,6 +131,35 @@ __global__ __launch_bounds__(256) void dense_scan_topk_kernel(const float* __res
   }
 }
 
+// Score an explicit candidate list: out[q][j] = <Q[q], X[rows[q][j]]> (rows < 0 -> -FLT_MAX).
+// One wave per (query, candidate): the row is gathered with three coalesced 1-KiB loads.
+// Stands where GraphRetriever re-embeds its candidates per query and takes cosines
+// (legalrag/retrieval/graph_retriever.py:177-191): the chunk embeddings are already in HBM.
+__global__ __launch_bounds__(256) void dense_score_rows_kernel(const float* __restrict__ X, long n, int d,
+                                                                const float* __restrict__ Q, int nq,
+                                                                const long long* __restrict__ rows, int m,
+                                                                float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long idx = (long)blockIdx.x * kWaves + wave;
+  if (idx >= (long)nq * m) return;
+  const int qi = (int)(idx / m);
+  const long long r = rows[idx];
+  if (r < 0 || r >= n) {
+    if (lane == 0) out[idx] = -FLT_MAX;
+    return;
+  }
+  const float* xr = X + (size_t)r * d;
+  const float* qr = Q + (size_t)qi * d;
+  float acc = 0.f;
+  for (int col = lane * 4; col < d; col += 256) {
+    const float4 a = *reinterpret_cast<const float4*>(xr + col);
+    const float4 b = *reinterpret_cast<const float4*>(qr + col);
+    acc = dot4(a, b, acc);
+  }
+  acc = wave_sum_to_lane63(acc);
+  if (lane == 63) out[idx] = acc;
+}
+
 // One block per query: stream the per-block lists, keep the best k, decode.
 __global__ __launch_bounds__(256) void dense_merge_kernel(const C32* __restrict__ part, int nparts, int nq, int k,
                                                            int cap, float* __restrict__ out_scores,
@@ -281,6 +310,7 @@ int make_plan(int64_t n, int d, int nq, int k, ScanPlan* p) {
   // round the slab to a multiple of the block's row stride so waves stay aligned
   long stride = (long)kWaves * U;
   p->rows_per_block = ((p->rows_per_block + stride - 1) / stride) * stride;
+  if (p->rows_per_block < stride) p->rows_per_block = stride;  // empty index: keep the divisor non-zero
   p->grid_x = (int)((n + p->rows_per_block - 1) / p->rows_per_block);
   if (p->grid_x < 1) p->grid_x = 1;
   p->grid_y = ceil_div(nq, nqb);
@@ -536,6 +566,29 @@ int amdr_dense_search(amdr_dense_t* h, const float* Q_host, int32_t nq, int32_t 
   if (rc) return rc;
   AMDR_HIP(hipMemcpyAsync(scores_host, h->sbuf.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   AMDR_HIP(hipMemcpyAsync(ids_host, h->ibuf.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+  AMDR_HIP(hipStreamSynchronize(h->stream));
+  return AMDR_OK;
+}
+
+int amdr_dense_score_rows(amdr_dense_t* h, const float* Q_host, int32_t nq, const int64_t* rows_host, int32_t m,
+                          float* scores_host) {
+  AMDR_REQUIRE(h != nullptr, "dense_score_rows: null handle");
+  AMDR_REQUIRE(nq >= 0 && m >= 0, "dense_score_rows: bad sizes");
+  if (nq == 0 || m == 0) return AMDR_OK;
+  AMDR_REQUIRE(Q_host && rows_host && scores_host, "dense_score_rows: null buffer");
+  std::lock_guard<std::mutex> g(h->mu);
+  AMDR_HIP(hipSetDevice(h->device));
+  int rc;
+  const size_t cnt = (size_t)nq * m;
+  if ((rc = h->qbuf.ensure((size_t)nq * h->d * sizeof(float)))) return rc;
+  if ((rc = h->sbuf.ensure(cnt * sizeof(float)))) return rc;
+  if ((rc = h->ibuf.ensure(cnt * sizeof(int64_t)))) return rc;
+  AMDR_HIP(hipMemcpyAsync(h->qbuf.p, Q_host, (size_t)nq * h->d * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  AMDR_HIP(hipMemcpyAsync(h->ibuf.p, rows_host, cnt * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(dense_score_rows_kernel, dim3(ceil_div((long)cnt, kWaves)), dim3(256), 0, h->stream, h->X,
+                     (long)h->n, h->d, h->qbuf.as<float>(), nq, h->ibuf.as<long long>(), m, h->sbuf.as<float>());
+  AMDR_HIP(hipGetLastError());
+  AMDR_HIP(hipMemcpyAsync(scores_host, h->sbuf.p, cnt * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   AMDR_HIP(hipStreamSynchronize(h->stream));
   return AMDR_OK;
 }

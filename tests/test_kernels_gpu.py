@@ -430,3 +430,28 @@ def test_bm25_fuzz_vs_oracle(nat):
             kk = min(k, n_docs)
             assert i[qn, :kk].tolist() == [e[0] for e in exp] and s[qn, :kk].tolist() == [e[1] for e in exp]
         gi.close()
+
+
+def test_dense_score_rows_and_edges(nat):
+    rng = np.random.default_rng(8)
+    X = unit_rows(rng, 500, 768)
+    Q = unit_rows(rng, 3, 768)
+    idx = nat.DenseIndex(X)
+    rows = rng.integers(-2, 520, size=(3, 37))
+    got = idx.score_rows(Q, rows)
+    ref = (Q.astype(np.float64) @ X.astype(np.float64).T)
+    for q in range(3):
+        for j, r in enumerate(rows[q]):
+            if 0 <= r < 500:
+                assert abs(got[q, j] - ref[q, r]) <= TOL
+            else:
+                assert got[q, j] == -np.finfo(np.float32).max
+    # empty index: every slot is padding; zero queries: no-op
+    e = nat.DenseIndex(dim=768)
+    s, i = e.search(Q, 5)
+    assert np.all(i == -1) and np.all(s == -np.finfo(np.float32).max) and e.ntotal == 0
+    e.add(X[:3])
+    s, i = e.search(Q[:1], 5)
+    assert sorted(i[0, :3].tolist()) == [0, 1, 2] and np.all(i[0, 3:] == -1)
+    s0, i0 = idx.search(np.zeros((0, 768), np.float32), 5)
+    assert s0.shape == (0, 5) and i0.shape == (0, 5)
