@@ -34,7 +34,7 @@ __device__ __forceinline__ long lower_bound_i32(const int* __restrict__ a, long 
   return lo;
 }
 
-// grid: (x = doc slabs, y = queries).  LDS: double sc[slab] + C64 lists[WAVES][cap] + int cnts[WAVES]
+// grid: (x = doc slabs, y = queries).  LDS: double sc[slab] + C64 lists[WAVES][cap] + int cnts[4] + token table [64]
 // WAVES = 1 for small slabs (one wave per query: no block barriers, no list combine),
 // 4 for full 4096-doc slabs.  With a single slab the final (scores, ids) are written
 // directly and the merge launch is skipped.
@@ -49,6 +49,9 @@ __global__ __launch_bounds__(WAVES * 64) void bm25_score_topk_kernel(
   double* sc = reinterpret_cast<double*>(smem);
   C64* lists = reinterpret_cast<C64*>(sc + slab);
   int* cnts = reinterpret_cast<int*>(lists + (size_t)WAVES * cap);
+  long* tk_ps = reinterpret_cast<long*>(cnts + 4);  // [64] posting range + idf of up to 64 query tokens
+  long* tk_pe = tk_ps + 64;
+  double* tk_w = reinterpret_cast<double*>(tk_pe + 64);
   constexpr int NT = WAVES * 64;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -61,21 +64,52 @@ __global__ __launch_bounds__(WAVES * 64) void bm25_score_topk_kernel(
   for (int i = tid; i < m; i += NT) sc[i] = 0.0;
   block_sync<WAVES>();
 
+  // Token metadata (posting range inside this slab, idf) is fetched by the lanes IN PARALLEL,
+  // 64 tokens at a time, and parked in LDS: walking the tokens one by one would chain three
+  // dependent global loads (term id -> term_ptr -> postings) per token, ~1.5 us each.
   const long t0 = q_ptr[qi], t1 = q_ptr[qi + 1];
-  for (long t = t0; t < t1; ++t) {
-    const int term = q_terms[t];
-    if (term < 0 || term >= n_terms) continue;  // unknown token: idf 0, contributes +0.0
-    const long p0 = term_ptr[term], p1 = term_ptr[term + 1];
-    const long ps = (lo == 0) ? p0 : lower_bound_i32(post_doc, p0, p1, (int)lo);
-    const double w = idf[term];
-    for (long p = ps + tid; p < p1; p += NT) {
-      const int doc = post_doc[p];
-      if (doc >= hi) break;
-      // rank_bm25: idf * (q_freq * (k1 + 1) / (q_freq + k1 * (1 - b + b * doc_len / avgdl)));
-      // the parenthesis depends only on (tf, doc) and is evaluated once at index creation
-      sc[doc - lo] += w * post_w[p];
+  for (long tb = t0; tb < t1; tb += 64) {
+    const int nt = (int)((t1 - tb) < 64 ? (t1 - tb) : 64);
+    if (tid < 64) {
+      long ps = 0, pe = 0;
+      double w = 0.0;
+      if (tid < nt) {
+        const int term = q_terms[tb + tid];
+        if (term >= 0 && term < n_terms) {  // unknown token: idf 0, contributes +0.0 -> skipped
+          const long p0 = term_ptr[term], p1 = term_ptr[term + 1];
+          ps = (lo == 0) ? p0 : lower_bound_i32(post_doc, p0, p1, (int)lo);
+          pe = (hi >= n_docs) ? p1 : lower_bound_i32(post_doc, ps, p1, (int)hi);
+          w = idf[term];
+        }
+      }
+      tk_ps[tid] = ps;
+      tk_pe[tid] = pe;
+      tk_w[tid] = w;
     }
     block_sync<WAVES>();
+    for (int t = 0; t < nt; ++t) {  // query order: this is the accumulation order of rank_bm25
+      const long ps = tk_ps[t], pe = tk_pe[t];
+      const double w = tk_w[t];
+      // rank_bm25: idf * (q_freq * (k1 + 1) / (q_freq + k1 * (1 - b + b * doc_len / avgdl))); the
+      // parenthesis depends only on (tf, doc) and was evaluated once at index creation.
+      // Four posting chunks are loaded before the first is applied (a list holds a document once,
+      // so the scatter has no conflicts and needs no ordering inside one token).
+      for (long p = ps + tid; p < pe; p += 4 * NT) {
+        int dd[4];
+        double ww[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const long pp = p + (long)u * NT;
+          const bool ok = pp < pe;
+          dd[u] = ok ? post_doc[pp] : -1;
+          ww[u] = ok ? post_w[pp] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (dd[u] >= 0) sc[dd[u] - lo] += w * ww[u];
+      }
+      block_sync<WAVES>();
+    }
   }
 
   if (scores_out) {
@@ -172,7 +206,8 @@ void bm_plan(int64_t n_docs, int nq, int k, BmPlan* p) {
   p->slab = n_docs < kSlabMax ? (int)(n_docs > 0 ? n_docs : 1) : kSlabMax;
   p->nslabs = n_docs > 0 ? (int)((n_docs + p->slab - 1) / p->slab) : 1;
   p->waves = p->slab <= 1024 ? 1 : kBmWaves;
-  p->lds = (size_t)p->slab * sizeof(double) + (size_t)p->waves * p->cap * sizeof(C64) + p->waves * sizeof(int);
+  p->lds = (size_t)p->slab * sizeof(double) + (size_t)p->waves * p->cap * sizeof(C64) + 4 * sizeof(int) +
+           64 * (2 * sizeof(long) + sizeof(double));
   p->part_bytes = (size_t)p->nslabs * nq * k * sizeof(C64);
 }
 

@@ -34,6 +34,7 @@ constexpr int kBW = 4;          // waves per block
 constexpr int kKC = 32;         // floats of every row per staged chunk (128 B = 8 slots of 16 B)
 constexpr int kStageBytes = 32 * kKC * 4;  // 4 KiB: one 32-row x 32-float chunk; each wave owns TWO (double buffer)
 constexpr int kPieces = kStageBytes / 1024;  // 1-KiB wave loads per chunk (4): 8 rows x 128 B each
+constexpr int kDepth = 4;                      // chunks in flight from HBM per wave (16 KiB)
 constexpr int kFr = kKC / 8;                  // float4 fragments per lane and chunk (4): its half of the 8 slots
 
 // LDS image of a staged chunk: row r (0..31) at byte r*128 — two rows share one 256-B bank
@@ -161,59 +162,46 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
       if (r >= row_hi) r = row_hi - 1;
       gp[p] = X + (size_t)r * d + lslot * 4;
     }
-    // Software pipeline (explicitly named even/odd register sets so nothing is indexed at run time):
-    //   Ga/Gb   chunk c / c+1 as they arrive from HBM (two chunks always in flight)
-    //   stage   this wave's two LDS images (even / odd chunk, swizzled)
-    //   FXa/FQa, FXb/FQb   MFMA fragments of the even / odd chunk, read from LDS one chunk
-    //   AHEAD of their use so the dependent MFMA chain never waits on an LDS round trip.
-    v4f Ga[kPieces], Gb[kPieces], FXa[kFr], FQa[kFr], FXb[kFr], FQb[kFr];
+    // Software pipeline; every index below is a compile-time constant once the chunk loop is
+    // unrolled, so the arrays live in registers:
+    //   G[c % kDepth]  chunk c as it arrives from HBM (kDepth chunks = 16 KiB per wave in flight)
+    //   stage[c & 1]   this wave's LDS image of chunk c (swizzled, double-buffered)
+    //   FX/FQ[c & 1]   MFMA fragments of chunk c, read from LDS one chunk AHEAD of their use so
+    //                  the dependent MFMA chain never waits on an LDS round trip.
+    v4f G[kDepth][kPieces], FX[2][kFr], FQ[2][kFr];
 #pragma unroll
-    for (int p = 0; p < kPieces; ++p) Ga[p] = AMDR_LDX(gp[p]);
-    if (NCH > 1) {
+    for (int j = 0; j < kDepth; ++j) {
+      if (j < NCH) {
 #pragma unroll
-      for (int p = 0; p < kPieces; ++p) Gb[p] = AMDR_LDX(gp[p] + kKC);
+        for (int p = 0; p < kPieces; ++p) G[j][p] = AMDR_LDX(gp[p] + j * kKC);
+      }
     }
-    AMDR_STAGE_CHUNK(stage, Ga)
-    if (NCH > 2) {
+    AMDR_STAGE_CHUNK(stage, G[0])
+    if (kDepth < NCH) {
 #pragma unroll
-      for (int p = 0; p < kPieces; ++p) Ga[p] = AMDR_LDX(gp[p] + 2 * kKC);
+      for (int p = 0; p < kPieces; ++p) G[0][p] = AMDR_LDX(gp[p] + kDepth * kKC);
     }
     wave_lds_fence();
-    AMDR_READ_FRAGS(stage, 0, FXa, FQa)
+    AMDR_READ_FRAGS(stage, 0, FX[0], FQ[0])
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < NCH; c += 2) {
-      // Each half step is ONE scheduling region: the 32 dependent MFMAs of the chunk in the
-      // chain, and in their shadow the staging of the next chunk (8 ds_write), the refill of
-      // its registers from HBM (8 loads) and its fragment reads (16 ds_read).  The LDS unit
-      // serves a wave's operations in order and the compiler keeps the may-alias write->read
-      // order on `stage`, so no fence is needed inside the region.
-      // ---- even chunk c in the chain; odd chunk c+1 prepared
+    for (int c = 0; c < NCH; ++c) {
+      // One scheduling region per chunk: the 16 dependent MFMAs of chunk c and, in their shadow,
+      // the staging of chunk c+1 (4 ds_write), the refill of its registers with chunk
+      // c+1+kDepth (4 loads) and its fragment reads (8 ds_read).  The LDS unit serves a wave's
+      // operations in order and the compiler keeps the may-alias write->read order on `stage`.
       if (c + 1 < NCH) {
-        AMDR_STAGE_CHUNK(stage + kStageBytes, Gb)
-        if (c + 3 < NCH) {
+        unsigned char* st_n = stage + ((c + 1) & 1) * kStageBytes;
+        AMDR_STAGE_CHUNK(st_n, G[(c + 1) % kDepth])
+        if (c + 1 + kDepth < NCH) {
 #pragma unroll
-          for (int p = 0; p < kPieces; ++p) Gb[p] = AMDR_LDX(gp[p] + (c + 3) * kKC);
+          for (int p = 0; p < kPieces; ++p) G[(c + 1) % kDepth][p] = AMDR_LDX(gp[p] + (c + 1 + kDepth) * kKC);
         }
-        AMDR_READ_FRAGS(stage + kStageBytes, c + 1, FXb, FQb)
+        AMDR_READ_FRAGS(st_n, c + 1, FX[(c + 1) & 1], FQ[(c + 1) & 1])
       }
-      AMDR_MFMA_CHUNK(FXa, FQa)
+      AMDR_MFMA_CHUNK(FX[c & 1], FQ[c & 1])
       AMDR_INTERLEAVE()
       wave_lds_fence();
-      // ---- odd chunk c+1 in the chain; even chunk c+2 prepared
-      if (c + 1 < NCH) {
-        if (c + 2 < NCH) {
-          AMDR_STAGE_CHUNK(stage, Ga)
-          if (c + 4 < NCH) {
-#pragma unroll
-            for (int p = 0; p < kPieces; ++p) Ga[p] = AMDR_LDX(gp[p] + (c + 4) * kKC);
-          }
-          AMDR_READ_FRAGS(stage, c + 2, FXa, FQa)
-        }
-        AMDR_MFMA_CHUNK(FXb, FQb)
-        AMDR_INTERLEAVE()
-        wave_lds_fence();
-      }
     }
     const long r = r0 + i;
     if (r < row_hi) {
