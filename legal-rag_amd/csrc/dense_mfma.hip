@@ -233,13 +233,30 @@ __global__ __launch_bounds__(WAVES * 64) void scores_slab_topk_kernel(const floa
   const float* row = S + (size_t)qi * n;
   WaveTopK<C32> tk;
   tk.init(lists + (size_t)wave * cap, cap, k);
-  for (long base = lo + (long)wave * 64; base < hi; base += (long)WAVES * 64) {
-    const long r = base + lane;
-    const bool v = r < hi;
-    C32 c = v ? C32::make(row[r], (u32)r) : C32::pad();
-    tk.push_lanes(c, v, lane);
+  bool done = false;
+  if (WAVES == 1 && k <= 64 && hi - lo <= 1024) {
+    // short row: register selector (topk.hpp); scratch = the upper half of the staging buffer
+    C32 keys[16];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const long r = lo + lane + 64 * v;
+      keys[v] = (r < hi) ? C32::make(row[r], (u32)r) : C32::pad();
+    }
+    const int got = wave_select_small<C32, 16>(keys, k, tk.buf + 64, lane, tk.buf);
+    if (got >= 0) {
+      tk.cnt = got;
+      done = true;
+    }
   }
-  tk.finalize(lane);
+  if (!done) {
+    for (long base = lo + (long)wave * 64; base < hi; base += (long)WAVES * 64) {
+      const long r = base + lane;
+      const bool v = r < hi;
+      C32 c = v ? C32::make(row[r], (u32)r) : C32::pad();
+      tk.push_lanes(c, v, lane);
+    }
+    tk.finalize(lane);
+  }
   if (WAVES > 1) block_combine_topk(tk, lists, cap, WAVES, wave, lane, cnts);
   if (wave == 0) {
     if (fin_ids) {

@@ -186,6 +186,80 @@ __device__ __forceinline__ void block_sync() {
     __syncthreads();
 }
 
+// ---------------------------------------------------------------------------
+// Short rows (n <= 64 * V, k <= 64): selection entirely in registers.
+//   1. every lane holds V candidates and takes its local best;
+//   2. the 64 local bests are sorted across the lanes (bitonic network on shuffles);
+//      the k-th of them, T, is a lower bound of the k-th best overall (k candidates >= T
+//      exist), so the answer lies among the candidates that are not worse than T — in
+//      expectation only a few more than k;
+//   3. those are compacted (ballot + prefix popcount) into a 64-entry LDS scratch, sorted
+//      with the same network, and the first k are the result.
+// Returns the number of valid results written, or -1 when more than 64 candidates survive
+// step 2 (caller falls back to the staged selector).  ~3x fewer instructions than two
+// LDS bitonic sorts for n ~ 600, k = 10.
+__device__ __forceinline__ C32 wave_xchg(const C32& v, int partner) {
+  C32 o;
+  const unsigned lo = __shfl((unsigned)(v.c & 0xffffffffull), partner);
+  const unsigned hi = __shfl((unsigned)(v.c >> 32), partner);
+  o.c = ((u64)hi << 32) | lo;
+  return o;
+}
+__device__ __forceinline__ C64 wave_xchg(const C64& v, int partner) {
+  C64 o;
+  const unsigned a = __shfl((unsigned)(v.key & 0xffffffffull), partner);
+  const unsigned b = __shfl((unsigned)(v.key >> 32), partner);
+  const unsigned c = __shfl((unsigned)((u64)v.idv & 0xffffffffull), partner);
+  const unsigned d = __shfl((unsigned)((u64)v.idv >> 32), partner);
+  o.key = ((u64)b << 32) | a;
+  o.idv = (long long)(((u64)d << 32) | c);
+  return o;
+}
+
+template <class C>
+__device__ inline C wave_sort64_desc(C v, int lane) {
+#pragma unroll
+  for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const C o = wave_xchg(v, lane ^ stride);
+      const bool keep_better = (((lane & size) == 0) == ((lane & stride) == 0));
+      const bool mine_better = better(v, o);
+      v = (keep_better == mine_better) ? v : o;
+    }
+  }
+  return v;
+}
+
+template <class C, int V>
+__device__ inline int wave_select_small(const C (&keys)[V], int k, C* scratch /* LDS, 64 entries */, int lane,
+                                        C* out_sorted /* LDS or registers' spill target: k entries */) {
+  C lbest = C::pad();
+#pragma unroll
+  for (int v = 0; v < V; ++v)
+    if (better(keys[v], lbest)) lbest = keys[v];
+  const C sorted_best = wave_sort64_desc(lbest, lane);
+  const C T = wave_xchg(sorted_best, k - 1 < 63 ? k - 1 : 63);  // k-th local best (pad if fewer)
+  int cnt = 0;
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const bool pass = !keys[v].is_pad() && !better(T, keys[v]);
+    const u64 m = __ballot(pass);
+    const int tot = __popcll(m);
+    if (cnt + tot > 64) return -1;
+    const u64 lt = (lane == 0) ? 0ull : (m & (~0ull >> (64 - lane)));
+    if (pass) scratch[cnt + __popcll(lt)] = keys[v];
+    cnt += tot;
+  }
+  wave_lds_fence();
+  C c = (lane < cnt) ? scratch[lane] : C::pad();
+  c = wave_sort64_desc(c, lane);
+  wave_lds_fence();
+  if (lane < k) out_sorted[lane] = c;
+  wave_lds_fence();
+  return cnt < k ? cnt : k;
+}
+
 // Merge the finalized lists of all waves of a block into wave 0's list.
 // Call with all threads; contains block barriers.  lists: [nwaves][stride]
 // where each wave's WaveTopK.buf == lists + wave*stride.
