@@ -13,6 +13,8 @@
 
 #include <cfloat>
 #include <cmath>
+#include <cstring>
+#include <vector>
 
 namespace amdr {
 
@@ -344,18 +346,60 @@ int fuse_check(const amdr_fuse_params_t* p, int nq, int kd, int kb, int kc) {
 
 // ---- host-pointer conveniences (single-query API path) ---------------------
 namespace {
-struct Tmp {
-  void* p = nullptr;
-  ~Tmp() {
-    if (p) (void)hipFree(p);
+// The host-pointer entry points stage through ONE grow-only device arena per calling thread
+// (ten hipMalloc/hipFree pairs per single-query call used to cost more than the kernel).
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0, used = 0;
+  int device = -1;
+  ~Arena() {
+    if (base) (void)hipFree(base);
+  }
+  int begin(int dev, size_t total) {
+    if (dev != device || total > cap) {
+      if (base) (void)hipFree(base);
+      base = nullptr;
+      cap = 0;
+      size_t want = total < (1u << 20) ? (1u << 20) : total;
+      AMDR_HIP(hipMalloc((void**)&base, want));
+      cap = want;
+      device = dev;
+    }
+    used = 0;
+    return AMDR_OK;
+  }
+  void* take(size_t bytes) {
+    void* p = base + used;
+    used += (bytes + 255) & ~(size_t)255;
+    return p;
   }
 };
-template <class T>
-int to_dev(Tmp& t, const T* src, size_t count, hipStream_t st) {
-  if (!count) return AMDR_OK;
-  AMDR_HIP(hipMalloc(&t.p, count * sizeof(T)));
-  if (src) AMDR_HIP(hipMemcpyAsync(t.p, src, count * sizeof(T), hipMemcpyHostToDevice, st));
-  return AMDR_OK;
+inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+Arena& arena() {
+  static thread_local Arena a;
+  return a;
+}
+}  // namespace
+
+// Host-pointer forms: inputs are packed into ONE pinned-size-agnostic host block and moved
+// with one H2D copy, outputs come back with one D2H copy (every extra small copy from
+// pageable memory costs ~10-15 us).
+namespace {
+struct Pack {
+  std::vector<char>& buf;
+  size_t used = 0;
+  explicit Pack(std::vector<char>& b) : buf(b) {}
+  size_t add(const void* src, size_t bytes) {
+    size_t off = used;
+    used += pad256(bytes);
+    if (buf.size() < used) buf.resize(used);
+    if (src && bytes) memcpy(buf.data() + off, src, bytes);
+    return off;
+  }
+};
+std::vector<char>& host_block() {
+  static thread_local std::vector<char> b;
+  return b;
 }
 }  // namespace
 
@@ -408,35 +452,38 @@ int amdr_fuse(const amdr_fuse_params_t* p, int32_t nq, const int64_t* dense_ids,
   int rc = fuse_check(p, nq, kd, kb, kc);
   if (rc) return rc;
   if (nq == 0) return AMDR_OK;
-  int dev = 0;
-  AMDR_HIP(hipGetDevice(&dev));
-  const int mo = kd + kb + kc;
-  Tmp di, ds, bi, bs, ci, cs, oi, ov, om, oc;
-  hipStream_t st = nullptr;
-  if ((rc = to_dev(di, dense_ids, (size_t)nq * kd, st))) return rc;
-  if ((rc = to_dev(ds, dense_scores, (size_t)nq * kd, st))) return rc;
-  if ((rc = to_dev(bi, bm25_ids, (size_t)nq * kb, st))) return rc;
-  if ((rc = to_dev(bs, bm25_scores, (size_t)nq * kb, st))) return rc;
-  if ((rc = to_dev(ci, colbert_ids, (size_t)nq * kc, st))) return rc;
-  if ((rc = to_dev(cs, colbert_scores, (size_t)nq * kc, st))) return rc;
-  if ((rc = to_dev(oi, (const int64_t*)nullptr, (size_t)nq * mo, st))) return rc;
-  if ((rc = to_dev(ov, (const double*)nullptr, (size_t)nq * mo * AMDR_FUSE_NVALS, st))) return rc;
-  if ((rc = to_dev(om, (const int32_t*)nullptr, (size_t)nq * mo, st))) return rc;
-  if ((rc = to_dev(oc, (const int32_t*)nullptr, (size_t)nq, st))) return rc;
   AMDR_REQUIRE((kd == 0 || (dense_ids && dense_scores)) && (kb == 0 || (bm25_ids && bm25_scores)) &&
                    (kc == 0 || (colbert_ids && colbert_scores)) && out_ids && out_vals && out_mask && out_count,
                "fuse: null buffer");
-  ChanIn c0{(const long long*)di.p, ds.p, nullptr, kd, 1};
-  ChanIn c1{(const long long*)bi.p, bs.p, nullptr, kb, 1};
-  ChanIn c2{(const long long*)ci.p, cs.p, nullptr, kc, 1};
-  hipLaunchKernelGGL(fuse_kernel, dim3(nq), dim3(64), (size_t)mo * 36, st, *p, c0, c1, c2, mo, (long long*)oi.p, (double*)ov.p,
-                     (int*)om.p, (int*)oc.p);
+  int dev = 0;
+  AMDR_HIP(hipGetDevice(&dev));
+  const size_t q = (size_t)nq, mo = (size_t)(kd + kb + kc);
+  Pack in(host_block());
+  const size_t o_di = in.add(dense_ids, q * kd * 8), o_ds = in.add(dense_scores, q * kd * 8);
+  const size_t o_bi = in.add(bm25_ids, q * kb * 8), o_bs = in.add(bm25_scores, q * kb * 8);
+  const size_t o_ci = in.add(colbert_ids, q * kc * 8), o_cs = in.add(colbert_scores, q * kc * 8);
+  const size_t in_bytes = in.used;
+  // outputs follow the inputs in the same device arena, contiguous so one copy brings them back
+  const size_t o_oi = in_bytes, o_ov = o_oi + pad256(q * mo * 8), o_om = o_ov + pad256(q * mo * AMDR_FUSE_NVALS * 8),
+               o_oc = o_om + pad256(q * mo * 4), total = o_oc + pad256(q * 4);
+  if ((rc = arena().begin(dev, total))) return rc;
+  char* d = arena().base;
+  hipStream_t st = nullptr;
+  AMDR_HIP(hipMemcpyAsync(d, host_block().data(), in_bytes, hipMemcpyHostToDevice, st));
+  ChanIn c0{(const long long*)(d + o_di), d + o_ds, nullptr, kd, 1};
+  ChanIn c1{(const long long*)(d + o_bi), d + o_bs, nullptr, kb, 1};
+  ChanIn c2{(const long long*)(d + o_ci), d + o_cs, nullptr, kc, 1};
+  hipLaunchKernelGGL(fuse_kernel, dim3(nq), dim3(64), mo * 36, st, *p, c0, c1, c2, (int)mo, (long long*)(d + o_oi),
+                     (double*)(d + o_ov), (int*)(d + o_om), (int*)(d + o_oc));
   AMDR_HIP(hipGetLastError());
-  AMDR_HIP(hipMemcpyAsync(out_ids, oi.p, (size_t)nq * mo * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-  AMDR_HIP(hipMemcpyAsync(out_vals, ov.p, (size_t)nq * mo * AMDR_FUSE_NVALS * sizeof(double), hipMemcpyDeviceToHost, st));
-  AMDR_HIP(hipMemcpyAsync(out_mask, om.p, (size_t)nq * mo * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-  AMDR_HIP(hipMemcpyAsync(out_count, oc.p, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  std::vector<char>& hb = host_block();
+  if (hb.size() < total) hb.resize(total);
+  AMDR_HIP(hipMemcpyAsync(hb.data() + o_oi, d + o_oi, total - o_oi, hipMemcpyDeviceToHost, st));
   AMDR_HIP(hipStreamSynchronize(st));
+  memcpy(out_ids, hb.data() + o_oi, q * mo * 8);
+  memcpy(out_vals, hb.data() + o_ov, q * mo * AMDR_FUSE_NVALS * 8);
+  memcpy(out_mask, hb.data() + o_om, q * mo * 4);
+  memcpy(out_count, hb.data() + o_oc, q * 4);
   return AMDR_OK;
 }
 
@@ -447,22 +494,29 @@ int amdr_rerank_blend(int32_t nq, int32_t max_out, const int32_t* count, int64_t
   AMDR_REQUIRE(count && ids && vals && mask && ce_raw && out_rerank, "rerank_blend: null buffer");
   int dev = 0, rc;
   AMDR_HIP(hipGetDevice(&dev));
-  Tmp dc, di, dv, dm, dr, dout;
+  const size_t q = (size_t)nq, mo = (size_t)max_out;
+  Pack in(host_block());
+  const size_t o_c = in.add(count, q * 4), o_r = in.add(ce_raw, q * top_n * 8);
+  // in/out arrays next, contiguous, so one copy each way covers ids, vals, mask (+ rerank out)
+  const size_t o_i = in.add(ids, q * mo * 8), o_v = in.add(vals, q * mo * AMDR_FUSE_NVALS * 8),
+               o_m = in.add(mask, q * mo * 4);
+  const size_t in_bytes = in.used;
+  const size_t o_o = in_bytes, total = o_o + pad256(q * mo * 16);
+  if ((rc = arena().begin(dev, total))) return rc;
+  char* d = arena().base;
   hipStream_t st = nullptr;
-  if ((rc = to_dev(dc, count, (size_t)nq, st))) return rc;
-  if ((rc = to_dev(di, ids, (size_t)nq * max_out, st))) return rc;
-  if ((rc = to_dev(dv, vals, (size_t)nq * max_out * AMDR_FUSE_NVALS, st))) return rc;
-  if ((rc = to_dev(dm, mask, (size_t)nq * max_out, st))) return rc;
-  if ((rc = to_dev(dr, ce_raw, (size_t)nq * top_n, st))) return rc;
-  if ((rc = to_dev(dout, (const double*)nullptr, (size_t)nq * max_out * 2, st))) return rc;
-  rc = amdr_rerank_blend_device(nq, max_out, (const int32_t*)dc.p, (int64_t*)di.p, (double*)dv.p, (int32_t*)dm.p,
-                                (const double*)dr.p, top_n, beta, (double*)dout.p, dev, st);
+  AMDR_HIP(hipMemcpyAsync(d, host_block().data(), in_bytes, hipMemcpyHostToDevice, st));
+  rc = amdr_rerank_blend_device(nq, max_out, (const int32_t*)(d + o_c), (int64_t*)(d + o_i), (double*)(d + o_v),
+                                (int32_t*)(d + o_m), (const double*)(d + o_r), top_n, beta, (double*)(d + o_o), dev, st);
   if (rc) return rc;
-  AMDR_HIP(hipMemcpyAsync(ids, di.p, (size_t)nq * max_out * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-  AMDR_HIP(hipMemcpyAsync(vals, dv.p, (size_t)nq * max_out * AMDR_FUSE_NVALS * sizeof(double), hipMemcpyDeviceToHost, st));
-  AMDR_HIP(hipMemcpyAsync(mask, dm.p, (size_t)nq * max_out * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-  AMDR_HIP(hipMemcpyAsync(out_rerank, dout.p, (size_t)nq * max_out * 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+  std::vector<char>& hb = host_block();
+  if (hb.size() < total) hb.resize(total);
+  AMDR_HIP(hipMemcpyAsync(hb.data() + o_i, d + o_i, total - o_i, hipMemcpyDeviceToHost, st));
   AMDR_HIP(hipStreamSynchronize(st));
+  memcpy(ids, hb.data() + o_i, q * mo * 8);
+  memcpy(vals, hb.data() + o_v, q * mo * AMDR_FUSE_NVALS * 8);
+  memcpy(mask, hb.data() + o_m, q * mo * 4);
+  memcpy(out_rerank, hb.data() + o_o, q * mo * 16);
   return AMDR_OK;
 }
 
