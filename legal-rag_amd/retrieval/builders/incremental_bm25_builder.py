@@ -15,7 +15,7 @@ from typing import List
 from ... import artifacts, text
 from ...bm25_model import BM25Okapi
 from ...schemas import LawChunk
-from ._incremental import incoming_chunks, unseen
+from ._incremental import incoming_chunks
 
 logger = logging.getLogger(__name__)
 

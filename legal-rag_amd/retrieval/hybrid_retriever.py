@@ -26,7 +26,7 @@ import math
 import time
 import traceback
 from dataclasses import dataclass
-from typing import Any, Dict, List, Optional, Sequence, Set, Tuple
+from typing import Any, Dict, List, Optional, Sequence, Set
 
 import numpy as np
 

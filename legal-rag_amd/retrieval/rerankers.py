@@ -19,7 +19,7 @@ import json
 import math
 import os
 import re
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Any, Dict, List, Optional, Protocol, Sequence, Tuple, Union
 
 TextLike = Union[str, Dict[str, Any]]
