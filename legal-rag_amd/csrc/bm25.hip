@@ -15,6 +15,7 @@
 #include "topk.hpp"
 
 #include <cfloat>
+#include <cmath>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -119,15 +120,61 @@ __global__ __launch_bounds__(WAVES * 64) void bm25_score_topk_kernel(
 
   WaveTopK<C64> tk;
   tk.init(lists + (size_t)wave * cap, cap, k);
-  // (the register selector of topk.hpp was measured here too: with 128-bit candidates its two
-  // shuffle networks cost more than the staged selector — 160 vs 98 us per 9 344 queries)
-  for (int base = wave * 64; base < m; base += WAVES * 64) {
-    int i = base + lane;
-    bool v = i < m;
-    C64 c = v ? C64::make(sc[i], lo + i) : C64::pad();
-    tk.push_lanes(c, v, lane);
+  // Short slab and shallow k (the serving shape: <= 1024 docs, k <= 16): k rounds of a wave-wide
+  // arg-max directly on the fp64 scores held in registers (16 per lane).  A round = lane-local
+  // v_max_f64 over 16 values, a 6-step butterfly, then the LOWEST position holding that value
+  // (ties -> lower doc id, as the stable sort of bm25_retriever.py:75) and its removal: ~80
+  // instructions, vs two LDS bitonic sorts of 128-bit candidates for the staged selector
+  // (measured 65 of the kernel's 98 us per 9 344 queries).  The register selector of topk.hpp
+  // was tried here too: with 128-bit candidates its two shuffle networks were slower still.
+  bool done = false;
+  if (WAVES == 1 && k <= 16 && m <= 1024) {
+    const double ninf = -INFINITY;
+    double sv[16];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int i = lane + 64 * v;
+      double x = (i < m) ? sc[i] + 0.0 : ninf;  // -0.0 -> +0.0
+      sv[v] = (x != x) ? -DBL_MAX : x;          // NaN ranks last among real documents
+    }
+    int got = 0;
+    for (int it = 0; it < k; ++it) {
+      double lm = sv[0];
+#pragma unroll
+      for (int v = 1; v < 16; ++v) lm = fmax(lm, sv[v]);
+      double wm = lm;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) wm = fmax(wm, __shfl_xor(wm, o));
+      if (wm == ninf) break;  // fewer than k documents in the slab
+      int pos = 0x7fffffff;
+#pragma unroll
+      for (int v = 15; v >= 0; --v)
+        if (sv[v] == wm) pos = lane + 64 * v;
+      int win = pos;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const int other = __shfl_xor(win, o);
+        win = other < win ? other : win;
+      }
+#pragma unroll
+      for (int v = 0; v < 16; ++v)
+        if (lane + 64 * v == win) sv[v] = ninf;
+      if (lane == 0) tk.buf[it] = C64::make(wm, lo + win);
+      got = it + 1;
+    }
+    wave_lds_fence();
+    tk.cnt = got;
+    done = true;
   }
-  tk.finalize(lane);
+  if (!done) {
+    for (int base = wave * 64; base < m; base += WAVES * 64) {
+      int i = base + lane;
+      bool v = i < m;
+      C64 c = v ? C64::make(sc[i], lo + i) : C64::pad();
+      tk.push_lanes(c, v, lane);
+    }
+    tk.finalize(lane);
+  }
   if (WAVES > 1) block_combine_topk(tk, lists, cap, WAVES, wave, lane, cnts);
   if (wave == 0) {
     if (fin_ids) {
