@@ -20,9 +20,16 @@
 #include <new>
 #include <vector>
 
+
 namespace amdr {
 
 constexpr int kBmWaves = 4;
+
+__device__ __forceinline__ long uniform_i64(long v) {  // value known to be the same in every lane -> scalar pair
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long)v & 0xffffffffu));
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long)v >> 32));
+  return (long)(((unsigned long)hi << 32) | lo);
+}
 
 __device__ __forceinline__ long lower_bound_i32(const int* __restrict__ a, long lo, long hi, int key) {
   while (lo < hi) {
@@ -33,6 +40,55 @@ __device__ __forceinline__ long lower_bound_i32(const int* __restrict__ a, long 
       hi = mid;
   }
   return lo;
+}
+
+// Top-k of a short score slab (m <= 64 * NV documents) by k rounds of a wave-wide arg-max on the
+// fp64 scores held in registers, NV per lane (document lane + 64 v in register v).  One round:
+//   lane maximum (NV-1 v_max_f64) -> wave maximum (6 exchange steps on DPP / permlane swaps)
+//   -> per register one v_cmp_eq against it; the 64-bit lane masks are SCALARS, so "lowest
+//   register with a hit, lowest lane in it" (ties -> lower doc id, the stable sort of
+//   bm25_retriever.py:75) is scalar-unit work and needs no second cross-lane reduction
+//   -> the winner's register is reset in its lane (two v_cndmask per register).
+// ~6 NV + 25 vector instructions per round; the staged selector of topk.hpp sorts 128-bit
+// candidates through LDS twice (measured 65 of the kernel's 98 us per 9 344 queries).
+// -0.0 is folded to +0.0 and NaN ranks below every real score, as C64::make orders them.
+template <int NV>
+__device__ __forceinline__ int bm25_argmax_rounds(const double* sc, int m, int k, long lo, int lane, C64* out) {
+  const double ninf = -INFINITY;
+  double sv[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int i = lane + 64 * v;
+    const double x = (i < m) ? sc[i] + 0.0 : ninf;
+    sv[v] = (x != x) ? -DBL_MAX : x;
+  }
+  int got = 0;
+#if defined(AMDR_BM_ABL) && AMDR_BM_ABL == 1
+  for (int it = 0; it < 1; ++it) {
+#else
+  for (int it = 0; it < k; ++it) {
+#endif
+    double lm = sv[0];
+#pragma unroll
+    for (int v = 1; v < NV; ++v) lm = max_f64_raw(lm, sv[v]);
+    const double wm = wave_allmax_f64(lm);
+    if (wm == ninf) break;  // fewer than k documents in the slab
+    unsigned long long fm = 0ull;
+    int fv = 0;
+#pragma unroll
+    for (int v = NV - 1; v >= 0; --v) {
+      const unsigned long long hit = __ballot(sv[v] == wm);
+      fm = hit ? hit : fm;
+      fv = hit ? v : fv;
+    }
+    const int wl = (int)__builtin_ctzll(fm);
+    const bool mine = (lane == wl);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) sv[v] = (mine && v == fv) ? ninf : sv[v];
+    if (lane == 0) out[it] = C64::make(wm, lo + wl + 64 * fv);
+    got = it + 1;
+  }
+  return got;
 }
 
 // grid: (x = doc slabs, y = queries).  LDS: double sc[slab] + C64 lists[WAVES][cap] + int cnts[4] + token table [64]
@@ -53,6 +109,7 @@ __global__ __launch_bounds__(WAVES * 64) void bm25_score_topk_kernel(
   long* tk_ps = reinterpret_cast<long*>(cnts + 4);  // [64] posting range + idf of up to 64 query tokens
   long* tk_pe = tk_ps + 64;
   double* tk_w = reinterpret_cast<double*>(tk_pe + 64);
+  int* tk_n = reinterpret_cast<int*>(tk_w + 64);  // tokens of the current group that have postings in this slab
   constexpr int NT = WAVES * 64;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -70,11 +127,11 @@ __global__ __launch_bounds__(WAVES * 64) void bm25_score_topk_kernel(
   // dependent global loads (term id -> term_ptr -> postings) per token, ~1.5 us each.
   const long t0 = q_ptr[qi], t1 = q_ptr[qi + 1];
   for (long tb = t0; tb < t1; tb += 64) {
-    const int nt = (int)((t1 - tb) < 64 ? (t1 - tb) : 64);
+    const int nt_all = (int)((t1 - tb) < 64 ? (t1 - tb) : 64);
     if (tid < 64) {
       long ps = 0, pe = 0;
       double w = 0.0;
-      if (tid < nt) {
+      if (tid < nt_all) {
         const int term = q_terms[tb + tid];
         if (term >= 0 && term < n_terms) {  // unknown token: idf 0, contributes +0.0 -> skipped
           const long p0 = term_ptr[term], p1 = term_ptr[term + 1];
@@ -83,31 +140,83 @@ __global__ __launch_bounds__(WAVES * 64) void bm25_score_topk_kernel(
           w = idf[term];
         }
       }
-      tk_ps[tid] = ps;
-      tk_pe[tid] = pe;
-      tk_w[tid] = w;
+      // Only tokens with postings in this slab are kept, in query order: a token without any adds
+      // nothing to any score (jieba's query tokens include every blank and punctuation mark —
+      // 13 of the 19 tokens of an average UCC-en query are unknown to the index).
+      const bool keep = pe > ps;
+      const unsigned long long km = __ballot(keep);
+      const unsigned long long below = (tid == 0) ? 0ull : (km & (~0ull >> (64 - tid)));
+      if (keep) {
+        const int at = __popcll(below);
+        tk_ps[at] = ps;
+        tk_pe[at] = pe;
+        tk_w[at] = w;
+      }
+      if (tid == 0) *tk_n = __popcll(km);
     }
     block_sync<WAVES>();
-    for (int t = 0; t < nt; ++t) {  // query order: this is the accumulation order of rank_bm25
-      const long ps = tk_ps[t], pe = tk_pe[t];
+    const int nt = __builtin_amdgcn_readfirstlane(*tk_n);
+    if (nt == 0) {
+      block_sync<WAVES>();  // the table is rewritten by the next group
+      continue;
+    }
+    // rank_bm25: idf * (q_freq * (k1 + 1) / (q_freq + k1 * (1 - b + b * doc_len / avgdl))); the
+    // parenthesis depends only on (tf, doc) and was evaluated once at index creation.
+    // Tokens are applied in query order (the accumulation order of rank_bm25); inside one token a
+    // list holds a document once, so the scatter has no conflicts and needs no ordering.  The
+    // list bounds are wave-uniform (scalar registers): the loops and the short-list case branch
+    // on scalars, a lane's offset is 32-bit, and out-of-range lanes read a clamped address and
+    // are masked at the update — no divergent branches around the loads.
+    // The first chunk of token t+1 is requested before token t is applied (its address needs
+    // only the LDS table), so the per-token chain  load -> LDS update -> fence  overlaps one
+    // L2 round trip with the previous token's work.  Prefetch loads are unconditional (clamped
+    // index; the arrays carry one padding element) so the compiler can count them in s_waitcnt.
+    long ps_n = uniform_i64(tk_ps[0]);
+    int len_n = __builtin_amdgcn_readfirstlane((int)(tk_pe[0] - tk_ps[0]));
+    int d_n;
+    double x_n;
+    {
+      int jj = tid < len_n ? tid : len_n - 1;
+      jj = jj < 0 ? 0 : jj;
+      d_n = post_doc[ps_n + jj];
+      x_n = post_w[ps_n + jj];
+    }
+#if defined(AMDR_BM_ABL) && AMDR_BM_ABL == 2
+    for (int t = 0; t < 0; ++t) {
+#else
+    for (int t = 0; t < nt; ++t) {
+#endif
+      const long ps = ps_n;
+      const int len = len_n;
+      const int dfirst = d_n;
+      const double xfirst = x_n;
       const double w = tk_w[t];
-      // rank_bm25: idf * (q_freq * (k1 + 1) / (q_freq + k1 * (1 - b + b * doc_len / avgdl))); the
-      // parenthesis depends only on (tf, doc) and was evaluated once at index creation.
-      // Four posting chunks are loaded before the first is applied (a list holds a document once,
-      // so the scatter has no conflicts and needs no ordering inside one token).
-      for (long p = ps + tid; p < pe; p += 4 * NT) {
+      if (t + 1 < nt) {
+        ps_n = uniform_i64(tk_ps[t + 1]);
+        len_n = __builtin_amdgcn_readfirstlane((int)(tk_pe[t + 1] - tk_ps[t + 1]));
+        int jj = tid < len_n ? tid : len_n - 1;
+        jj = jj < 0 ? 0 : jj;
+        d_n = post_doc[ps_n + jj];
+        x_n = post_w[ps_n + jj];
+      }
+      if (tid < len) sc[dfirst - lo] += w * xfirst;
+      const int* __restrict__ pd = post_doc + ps;
+      const double* __restrict__ pw = post_w + ps;
+      for (int base = NT; base < len; base += 4 * NT) {  // lists longer than one chunk: four in flight
         int dd[4];
         double ww[4];
+        bool ok[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const long pp = p + (long)u * NT;
-          const bool ok = pp < pe;
-          dd[u] = ok ? post_doc[pp] : -1;
-          ww[u] = ok ? post_w[pp] : 0.0;
+          const int j = base + u * NT + tid;
+          ok[u] = j < len;
+          const int jj = ok[u] ? j : len - 1;
+          dd[u] = pd[jj];
+          ww[u] = pw[jj];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-          if (dd[u] >= 0) sc[dd[u] - lo] += w * ww[u];
+          if (ok[u]) sc[dd[u] - lo] += w * ww[u];
       }
       block_sync<WAVES>();
     }
@@ -120,48 +229,21 @@ __global__ __launch_bounds__(WAVES * 64) void bm25_score_topk_kernel(
 
   WaveTopK<C64> tk;
   tk.init(lists + (size_t)wave * cap, cap, k);
-  // Short slab and shallow k (the serving shape: <= 1024 docs, k <= 16): k rounds of a wave-wide
-  // arg-max directly on the fp64 scores held in registers (16 per lane).  A round = lane-local
-  // v_max_f64 over 16 values, a 6-step butterfly, then the LOWEST position holding that value
-  // (ties -> lower doc id, as the stable sort of bm25_retriever.py:75) and its removal: ~80
-  // instructions, vs two LDS bitonic sorts of 128-bit candidates for the staged selector
-  // (measured 65 of the kernel's 98 us per 9 344 queries).  The register selector of topk.hpp
-  // was tried here too: with 128-bit candidates its two shuffle networks were slower still.
+  // Short slab and shallow k (the serving shape: <= 1024 docs, k <= 16): bm25_argmax_rounds.
   bool done = false;
   if (WAVES == 1 && k <= 16 && m <= 1024) {
-    const double ninf = -INFINITY;
-    double sv[16];
-#pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      const int i = lane + 64 * v;
-      double x = (i < m) ? sc[i] + 0.0 : ninf;  // -0.0 -> +0.0
-      sv[v] = (x != x) ? -DBL_MAX : x;          // NaN ranks last among real documents
-    }
-    int got = 0;
-    for (int it = 0; it < k; ++it) {
-      double lm = sv[0];
-#pragma unroll
-      for (int v = 1; v < 16; ++v) lm = fmax(lm, sv[v]);
-      double wm = lm;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) wm = fmax(wm, __shfl_xor(wm, o));
-      if (wm == ninf) break;  // fewer than k documents in the slab
-      int pos = 0x7fffffff;
-#pragma unroll
-      for (int v = 15; v >= 0; --v)
-        if (sv[v] == wm) pos = lane + 64 * v;
-      int win = pos;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const int other = __shfl_xor(win, o);
-        win = other < win ? other : win;
-      }
-#pragma unroll
-      for (int v = 0; v < 16; ++v)
-        if (lane + 64 * v == win) sv[v] = ninf;
-      if (lane == 0) tk.buf[it] = C64::make(wm, lo + win);
-      got = it + 1;
-    }
+    const int nv = (m + 63) >> 6;
+    int got;
+    if (nv <= 4)
+      got = bm25_argmax_rounds<4>(sc, m, k, lo, lane, tk.buf);
+    else if (nv <= 8)
+      got = bm25_argmax_rounds<8>(sc, m, k, lo, lane, tk.buf);
+    else if (nv <= 10)
+      got = bm25_argmax_rounds<10>(sc, m, k, lo, lane, tk.buf);
+    else if (nv <= 12)
+      got = bm25_argmax_rounds<12>(sc, m, k, lo, lane, tk.buf);
+    else
+      got = bm25_argmax_rounds<16>(sc, m, k, lo, lane, tk.buf);
     wave_lds_fence();
     tk.cnt = got;
     done = true;
@@ -255,8 +337,12 @@ void bm_plan(int64_t n_docs, int nq, int k, BmPlan* p) {
   p->slab = n_docs < kSlabMax ? (int)(n_docs > 0 ? n_docs : 1) : kSlabMax;
   p->nslabs = n_docs > 0 ? (int)((n_docs + p->slab - 1) / p->slab) : 1;
   p->waves = p->slab <= 1024 ? 1 : kBmWaves;
+  // short slab + shallow k: the kernel ranks in registers and parks only the k winners in LDS,
+  // so the candidate list shrinks from cap to 16 entries (8.3 -> 6.5 KiB per block at UCC-en
+  // size: 24 instead of 19 resident waves per CU)
+  if (p->waves == 1 && k <= 16) p->cap = 16;
   p->lds = (size_t)p->slab * sizeof(double) + (size_t)p->waves * p->cap * sizeof(C64) + 4 * sizeof(int) +
-           64 * (2 * sizeof(long) + sizeof(double));
+           64 * (2 * sizeof(long) + sizeof(double)) + 8;
   p->part_bytes = (size_t)p->nslabs * nq * k * sizeof(C64);
 }
 
@@ -295,7 +381,7 @@ int bm_run(amdr_bm25* h, const int* q_terms_dev, const long long* q_ptr_dev, int
 template <class T>
 int upload(T** dst, const T* src, size_t count) {
   *dst = nullptr;
-  size_t bytes = (count ? count : 1) * sizeof(T);
+  size_t bytes = (count + 1) * sizeof(T);  // one padding element: clamped prefetch reads may touch [count]
   AMDR_HIP(hipMalloc((void**)dst, bytes));
   if (count) AMDR_HIP(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
   return AMDR_OK;

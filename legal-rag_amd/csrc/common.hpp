@@ -67,7 +67,8 @@ int check_device(int device);
 
 // ---- batched (32-query tile, fp32 MFMA) dense path: dense_mfma.hip -----------
 struct DenseMfmaPlan {
-  int q_tiles, grid_x, slabs, cap, waves;
+  int q_tiles, grid_x, grid_y, slabs, cap, waves;
+  bool transposed;  // chunk tiles held in LDS, queries streamed (short corpus, long batch)
   long rows_per_block, rows_per_slab;
   size_t lds_scores, s_bytes, part_bytes;
 };

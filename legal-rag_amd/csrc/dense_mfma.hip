@@ -24,6 +24,7 @@
 #include "topk.hpp"
 
 #include <cfloat>
+#include <cstdlib>
 
 namespace amdr {
 
@@ -97,11 +98,19 @@ __device__ __forceinline__ int stage_off(int row, int slot) { return row * 128 +
 
 // grid: (x = row slabs, y = 32-query tiles).
 // LDS: Q tile row-major [32][d/4] float4, slots XOR-swizzled per row (d*128 B) + per wave two private 4-KiB chunk stages.
-template <int D8, int WAVES>  // D8 = d / 8; WAVES = 8 when the Q tile leaves room for 8 stages (d <= 768)
+//
+// TR = true swaps the roles (the MFMA is symmetric in its two operands): the caller passes
+// the QUERY matrix as the streamed operand X and the CHUNK matrix as the tiled operand Q, so
+// a block keeps 32 chunk rows in LDS and its waves stream query tiles past them.  That is the
+// better decomposition for a short corpus under a long query batch (UCC-en: 19 row tiles x
+// 292 query tiles — 19 does not split evenly over 8 waves, 292 does).  The accumulator then
+// holds C[chunk row][query]; it is transposed through the wave's own stage so that S keeps
+// its [query][chunk row] layout and 128-byte stores.
+template <int D8, int WAVES, bool TR>  // D8 = d / 8; WAVES = 8 when the Q tile leaves room for 8 stages (d <= 768)
 __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const float* __restrict__ X, long n,
                                                                  const float* __restrict__ Q, int nq,
                                                                  long rows_per_block,
-                                                                 float* __restrict__ S /*[nq, n]*/) {
+                                                                 float* __restrict__ S /*[nq, n]; TR: [n, nq]*/) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int d = D8 * 8;
   constexpr int NCH = d / kKC;  // chunks per row: 12 / 24 / 32 (always even: d % 64 == 0)
@@ -203,13 +212,30 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
       AMDR_INTERLEAVE()
       wave_lds_fence();
     }
-    const long r = r0 + i;
-    if (r < row_hi) {
+    if (!TR) {
+      const long r = r0 + i;
+      if (r < row_hi) {
 #pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const int qrow = (g & 3) + 8 * (g >> 2) + 4 * h;  // C/D map: row = query within the tile
-        if (q0 + qrow < nq) S[(size_t)(q0 + qrow) * n + r] = acc[g];
+        for (int g = 0; g < 16; ++g) {
+          const int qrow = (g & 3) + 8 * (g >> 2) + 4 * h;  // C/D map: row = query within the tile
+          if (q0 + qrow < nq) S[(size_t)(q0 + qrow) * n + r] = acc[g];
+        }
       }
+    } else {
+      // lane i holds streamed row r0+i (a query) against the 16 tiled rows qrow(g, h) (chunks):
+      // park the 32x32 tile in the wave's stages as T[i][qrow] (row pitch 33 floats: 4 224 B of
+      // the 8 KiB), read it back with the chunk index on the lane, store 2 x 128 B per instruction.
+      float* tf = reinterpret_cast<float*>(stage);
+#pragma unroll
+      for (int g = 0; g < 16; ++g) tf[i * 33 + (g & 3) + 8 * (g >> 2) + 4 * h] = acc[g];
+      wave_lds_fence();
+#pragma unroll
+      for (int p = 0; p < 16; ++p) {
+        const int rr = 2 * p + h;
+        const float v = tf[rr * 33 + i];
+        if (r0 + rr < row_hi && q0 + i < nq) S[(size_t)(r0 + rr) * nq + q0 + i] = v;
+      }
+      wave_lds_fence();  // the next tile's first chunk is staged over T
     }
   }
 }
@@ -282,31 +308,60 @@ static int scores_waves(int d) {
   return w > 8 ? 8 : w;  // d <= 768: 8 waves (two per SIMD); d = 1024: 4
 }
 
-void dense_mfma_plan(long n, int d, int nq, int k, DenseMfmaPlan* p) {
-  const int kBW = scores_waves(d);
-  p->q_tiles = ceil_div(nq, 32);
-  long tiles = (n + 31) / 32;
-  // Row slabs per query tile: one block per CU is resident (the Q tile fills most of the
-  // LDS), a block costs (tiles per wave) tile-times plus ~1/4 tile-time to stage Q, and
-  // blocks run in rounds of 256.  Pick the slab count with the smallest estimate.
-  long gx_max = (tiles + kBW - 1) / kBW;  // at least one tile per wave
+// One orientation of the tile product: `tiles` 32-row tiles of the streamed operand are cut
+// into gx slabs per tile of the operand held in LDS (`fixed_tiles` of them).  One block per CU
+// is resident (the LDS tile fills most of the LDS), a block costs (tiles per wave) tile-times
+// plus ~1/4 tile-time to stage its LDS tile, and blocks run in rounds of 256.  Returns the
+// slab count with the smallest estimate.
+static long plan_orientation(long tiles, long fixed_tiles, int waves, double* est_out) {
+  long gx_max = (tiles + waves - 1) / waves;  // at least one tile per wave
   if (gx_max < 1) gx_max = 1;
   long gx = 1;
   double best = 1e300;
   for (long g = 1; g <= gx_max && g <= 4096; ++g) {
     long tpb = (tiles + g - 1) / g;
-    long per_wave = (tpb + kBW - 1) / kBW;
-    long rounds = ((long)p->q_tiles * g + 255) / 256;
+    long per_wave = (tpb + waves - 1) / waves;
+    long rounds = (fixed_tiles * g + 255) / 256;
     double est = (double)rounds * ((double)per_wave + 0.25);
     if (est < best - 1e-9) {
       best = est;
       gx = g;
     }
   }
-  long tiles_per_block = (tiles + gx - 1) / gx;
-  tiles_per_block = ((tiles_per_block + kBW - 1) / kBW) * kBW;
-  p->rows_per_block = tiles_per_block * 32;
-  p->grid_x = (int)((n + p->rows_per_block - 1) / p->rows_per_block);
+  *est_out = best;
+  return gx;
+}
+
+void dense_mfma_plan(long n, int d, int nq, int k, DenseMfmaPlan* p) {
+  const int kBW = scores_waves(d);
+  p->q_tiles = ceil_div(nq, 32);
+  long tiles = (n + 31) / 32;
+  double est_n, est_t;
+  long gx = plan_orientation(tiles, p->q_tiles, kBW, &est_n);
+  // Roles swapped (chunk tiles in LDS, queries streamed): taken when it balances clearly better,
+  // which is the short-corpus / long-batch case; never for a corpus of more than 64 Ki rows.
+  // AMDR_DENSE_ORIENT=n|t pins the choice (tests drive both orientations over the same shapes).
+  p->transposed = false;
+  const char* pin = getenv("AMDR_DENSE_ORIENT");
+  const bool pin_t = pin && pin[0] == 't', pin_n = pin && pin[0] == 'n';
+  if (tiles <= 2048 && !pin_n && (pin_t || p->q_tiles >= kBW)) {
+    long gxt = plan_orientation(p->q_tiles, tiles, kBW, &est_t);
+    if (pin_t || est_t < 0.9 * est_n) {
+      p->transposed = true;
+      long tpb = (p->q_tiles + gxt - 1) / gxt;
+      tpb = ((tpb + kBW - 1) / kBW) * kBW;
+      p->rows_per_block = tpb * 32;
+      p->grid_x = (int)(((long)nq + p->rows_per_block - 1) / p->rows_per_block);
+      p->grid_y = (int)tiles;
+    }
+  }
+  if (!p->transposed) {
+    long tiles_per_block = (tiles + gx - 1) / gx;
+    tiles_per_block = ((tiles_per_block + kBW - 1) / kBW) * kBW;
+    p->rows_per_block = tiles_per_block * 32;
+    p->grid_x = (int)((n + p->rows_per_block - 1) / p->rows_per_block);
+    p->grid_y = p->q_tiles;
+  }
   if (p->grid_x < 1) p->grid_x = 1;
   p->lds_scores = (size_t)d * 32 * sizeof(float) + (size_t)kBW * 2 * kStageBytes;
   p->waves = kBW;
@@ -323,24 +378,35 @@ void dense_mfma_plan(long n, int d, int nq, int k, DenseMfmaPlan* p) {
   p->part_bytes = (size_t)p->slabs * nq * k * sizeof(C32);
 }
 
-template <int D8, int WAVES>
+template <int D8, int WAVES, bool TR>
 static void launch_scores(const DenseMfmaPlan& p, const float* X, long n, const float* Q, int nq, float* S,
                           hipStream_t st) {
   static bool attr_done = false;  // 128-160 KiB of dynamic LDS needs the opt-in once per kernel
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)dense_mfma_scores_kernel<D8, WAVES>,
+    (void)hipFuncSetAttribute((const void*)dense_mfma_scores_kernel<D8, WAVES, TR>,
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               D8 * 8 * 32 * (int)sizeof(float) + WAVES * 2 * kStageBytes);
     attr_done = true;
   }
-  hipLaunchKernelGGL((dense_mfma_scores_kernel<D8, WAVES>), dim3(p.grid_x, p.q_tiles), dim3(WAVES * 64),
-                     p.lds_scores, st, X, n, Q, nq, p.rows_per_block, S);
+  // TR: the query matrix is the streamed operand, the chunk matrix the tiled one
+  if (TR)
+    hipLaunchKernelGGL((dense_mfma_scores_kernel<D8, WAVES, true>), dim3(p.grid_x, p.grid_y), dim3(WAVES * 64),
+                       p.lds_scores, st, Q, (long)nq, X, (int)n, p.rows_per_block, S);
+  else
+    hipLaunchKernelGGL((dense_mfma_scores_kernel<D8, WAVES, false>), dim3(p.grid_x, p.grid_y), dim3(WAVES * 64),
+                       p.lds_scores, st, X, n, Q, nq, p.rows_per_block, S);
 }
 
 int dense_mfma_launch_scores(const DenseMfmaPlan& p, const float* X, long n, int d, const float* Q, int nq, float* S,
                              hipStream_t st) {
   switch (d) {
-#define AMDR_CASE(D, W) case D: launch_scores<D / 8, W>(p, X, n, Q, nq, S, st); break;
+#define AMDR_CASE(D, W)                                              \
+  case D:                                                            \
+    if (p.transposed)                                                \
+      launch_scores<D / 8, W, true>(p, X, n, Q, nq, S, st);          \
+    else                                                             \
+      launch_scores<D / 8, W, false>(p, X, n, Q, nq, S, st);         \
+    break;
     AMDR_CASE(64, 8) AMDR_CASE(128, 8) AMDR_CASE(192, 8) AMDR_CASE(256, 8) AMDR_CASE(320, 8) AMDR_CASE(384, 8)
     AMDR_CASE(448, 8) AMDR_CASE(512, 8) AMDR_CASE(576, 8) AMDR_CASE(640, 8) AMDR_CASE(704, 8) AMDR_CASE(768, 8)
     AMDR_CASE(832, 7) AMDR_CASE(896, 6) AMDR_CASE(960, 5) AMDR_CASE(1024, 4)

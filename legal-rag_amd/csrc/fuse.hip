@@ -10,6 +10,7 @@
 // file is compiled with -ffp-contract=off so results are bit-identical to the
 // Python float arithmetic.  Exactly tied scores keep first-appearance order.
 #include "common.hpp"
+#include "topk.hpp"
 
 #include <cfloat>
 #include <cmath>
@@ -20,16 +21,9 @@ namespace amdr {
 
 constexpr int kFuseMax = 3 * AMDR_MAX_K;  // 768
 
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
-  return v;
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-  return v;
-}
+// all-lanes reductions on DPP / permlane-swap exchanges (topk.hpp), not ds_bpermute
+__device__ __forceinline__ double wave_min(double v) { return wave_allmin_f64(v); }
+__device__ __forceinline__ double wave_max(double v) { return wave_allmax_f64(v); }
 __device__ __forceinline__ void lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -84,9 +78,7 @@ __global__ __launch_bounds__(64) void fuse_kernel(amdr_fuse_params_t P, ChanIn c
         mx = fmax(mx, s);
       }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-    n[c] = cnt;
+    n[c] = wave_allsum_i32(cnt);
     lo[c] = wave_min(mn);
     hi[c] = wave_max(mx);
   }
@@ -203,35 +195,59 @@ __global__ __launch_bounds__(64) void fuse_kernel(amdr_fuse_params_t P, ChanIn c
     val[AMDR_FV_CONTRIB_COLBERT] = con[2];
   };
 
-  for (int u = lane; u < U; u += 64) {
-    double val[AMDR_FUSE_NVALS];
-    int mk;
-    eval(u, val, mk);
-    sc[u] = val[AMDR_FV_SCORE];
-  }
-  lds_sync();
-
-  // ---- stable descending rank, filter, scatter ---------------------------
+  // ---- score, stable descending rank, filter, scatter ---------------------
   int kept = 0;
   const size_t obase = (size_t)qi * max_out;
-  for (int u = lane; u < U; u += 64) {
+  if (U <= 64) {
+    // one candidate per lane (the serving shape: <= 3 x top-k ids): evaluate once, keep the nine
+    // values in registers across the rank computation
     double val[AMDR_FUSE_NVALS];
-    int mk;
-    eval(u, val, mk);
-    const double s = val[AMDR_FV_SCORE];
-    int r = 0;
-    for (int v2 = 0; v2 < U; ++v2) {
-      const double o = sc[v2];
-      r += (o > s) || (o == s && v2 < u);
+    int mk = 0;
+    const int u = lane;
+    if (u < U) {
+      eval(u, val, mk);
+      sc[u] = val[AMDR_FV_SCORE];
     }
-    if (s >= P.min_final_score) kept++;
-    out_ids[obase + r] = uid[u];
-    out_mask[obase + r] = mk;
+    lds_sync();
+    if (u < U) {
+      const double s = val[AMDR_FV_SCORE];
+      int r = 0;
+      for (int v2 = 0; v2 < U; ++v2) {
+        const double o = sc[v2];
+        r += (o > s) || (o == s && v2 < u);
+      }
+      if (s >= P.min_final_score) kept++;
+      out_ids[obase + r] = uid[u];
+      out_mask[obase + r] = mk;
 #pragma unroll
-    for (int x = 0; x < AMDR_FUSE_NVALS; ++x) out_vals[(obase + r) * AMDR_FUSE_NVALS + x] = val[x];
+      for (int x = 0; x < AMDR_FUSE_NVALS; ++x) out_vals[(obase + r) * AMDR_FUSE_NVALS + x] = val[x];
+    }
+  } else {
+    for (int u = lane; u < U; u += 64) {
+      double val[AMDR_FUSE_NVALS];
+      int mk;
+      eval(u, val, mk);
+      sc[u] = val[AMDR_FV_SCORE];
+    }
+    lds_sync();
+    for (int u = lane; u < U; u += 64) {
+      double val[AMDR_FUSE_NVALS];
+      int mk;
+      eval(u, val, mk);
+      const double s = val[AMDR_FV_SCORE];
+      int r = 0;
+      for (int v2 = 0; v2 < U; ++v2) {
+        const double o = sc[v2];
+        r += (o > s) || (o == s && v2 < u);
+      }
+      if (s >= P.min_final_score) kept++;
+      out_ids[obase + r] = uid[u];
+      out_mask[obase + r] = mk;
+#pragma unroll
+      for (int x = 0; x < AMDR_FUSE_NVALS; ++x) out_vals[(obase + r) * AMDR_FUSE_NVALS + x] = val[x];
+    }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o);
+  kept = wave_allsum_i32(kept);
   for (int r = U + lane; r < max_out; r += 64) {
     out_ids[obase + r] = -1;
     out_mask[obase + r] = 0;

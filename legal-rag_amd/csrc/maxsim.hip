@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void maxsim_scores_kernel(const float* __restr
     }
   }
   // the other half of the wave holds the complementary token rows of the same q-token
-  float other = __shfl_xor(best, 32);
+  float other = __uint_as_float(lane_xor<32>(__float_as_uint(best)));
   best = fmaxf(best, other);
   float contrib = (h == 0 && r < q_len) ? best : 0.f;
   float total = ms_wave_sum(contrib);

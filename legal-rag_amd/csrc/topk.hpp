@@ -216,13 +216,134 @@ __device__ __forceinline__ C64 wave_xchg(const C64& v, int partner) {
   return o;
 }
 
+// Value of lane (l ^ S) for a compile-time S, without the LDS crossbar: ds_bpermute (what
+// __shfl compiles to) costs a ~100-cycle LDS round trip per 32-bit word, and the selection
+// networks below are chains of dependent exchanges.  Strides inside a 16-lane row are DPP
+// moves (1-2 VALU ops); strides 16 and 32 use gfx950's v_permlane{16,32}_swap, which leaves
+// {own, partner} in its two results in a lane-dependent order — x ^ a ^ b is the partner either way.
+typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
+template <int S>
+__device__ __forceinline__ u32 lane_xor(u32 x) {
+  static_assert(S == 1 || S == 2 || S == 4 || S == 8 || S == 16 || S == 32, "stride");
+  if constexpr (S == 1) {
+    return (u32)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+  } else if constexpr (S == 2) {
+    return (u32)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+  } else if constexpr (S == 4) {
+    const int t = __builtin_amdgcn_update_dpp((int)x, (int)x, 0x104, 0xf, 0x5, false);  // row_shl:4 -> banks 0,2
+    return (u32)__builtin_amdgcn_update_dpp(t, (int)x, 0x114, 0xf, 0xa, false);          // row_shr:4 -> banks 1,3
+  } else if constexpr (S == 8) {
+    return (u32)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x128, 0xf, 0xf, false);  // row_ror:8
+  } else if constexpr (S == 16) {
+    const u32x2_t r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    return x ^ r.x ^ r.y;
+  } else {
+    const u32x2_t r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return x ^ r.x ^ r.y;
+  }
+}
+// stride known after unrolling: the switch folds away
+__device__ __forceinline__ u32 lane_xor_sw(u32 x, int s) {
+  switch (s) {
+    case 1: return lane_xor<1>(x);
+    case 2: return lane_xor<2>(x);
+    case 4: return lane_xor<4>(x);
+    case 8: return lane_xor<8>(x);
+    case 16: return lane_xor<16>(x);
+    default: return lane_xor<32>(x);
+  }
+}
+__device__ __forceinline__ u64 lane_xor_sw(u64 x, int s) {
+  return ((u64)lane_xor_sw((u32)(x >> 32), s) << 32) | lane_xor_sw((u32)x, s);
+}
+__device__ __forceinline__ C32 wave_xchg_xor(const C32& v, int s) {
+  C32 o;
+  o.c = lane_xor_sw(v.c, s);
+  return o;
+}
+__device__ __forceinline__ C64 wave_xchg_xor(const C64& v, int s) {
+  C64 o;
+  o.key = lane_xor_sw(v.key, s);
+  o.idv = (long long)lane_xor_sw((u64)v.idv, s);
+  return o;
+}
+// broadcast of one lane's value; `src` must be wave-uniform (v_readlane)
+__device__ __forceinline__ u64 wave_bcast_u64(u64 x, int src) {
+  const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)x, src);
+  const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(x >> 32), src);
+  return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ C32 wave_bcast(const C32& v, int src) {
+  C32 o;
+  o.c = wave_bcast_u64(v.c, src);
+  return o;
+}
+__device__ __forceinline__ C64 wave_bcast(const C64& v, int src) {
+  C64 o;
+  o.key = wave_bcast_u64(v.key, src);
+  o.idv = (long long)wave_bcast_u64((u64)v.idv, src);
+  return o;
+}
+// fp64 max / min as ONE instruction.  fmax()/fmin() make hipcc canonicalise both operands
+// first (a v_max_f64 x, x, x each) because it cannot prove them free of signalling NaNs across
+// a loop; every value that reaches these helpers was produced by arithmetic, so it is.
+__device__ __forceinline__ double max_f64_raw(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double min_f64_raw(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {  // every lane valid for the controls used below
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// All-lanes max / min of an fp64: four DPP steps reduce each 16-lane row (quad pairs, quad
+// halves, then row_half_mirror and row_mirror — any pairing that joins the halves will do for
+// a reduction), the four row results are read into scalar registers and combined.  The
+// result is wave-uniform by construction (the compiler keeps it in SGPRs).
+#define AMDR_WAVE_REDUCE_F64(NAME, OP)                                                        \
+  __device__ __forceinline__ double NAME(double x) {                                          \
+    x = OP(x, dpp_f64<0xB1>(x));  /* quad_perm [1,0,3,2] */                                   \
+    x = OP(x, dpp_f64<0x4E>(x));  /* quad_perm [2,3,0,1] */                                   \
+    x = OP(x, dpp_f64<0x141>(x)); /* row_half_mirror */                                       \
+    x = OP(x, dpp_f64<0x140>(x)); /* row_mirror */                                            \
+    const int lo = __double2loint(x), hi = __double2hiint(x);                                 \
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));   \
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16)); \
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32)); \
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48)); \
+    return OP(OP(r0, r1), OP(r2, r3));                                                        \
+  }
+AMDR_WAVE_REDUCE_F64(wave_allmax_f64, max_f64_raw)
+AMDR_WAVE_REDUCE_F64(wave_allmin_f64, min_f64_raw)
+#undef AMDR_WAVE_REDUCE_F64
+__device__ __forceinline__ int wave_allsum_i32(int x) {
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) x += (int)lane_xor_sw((u32)x, s);
+  return x;
+}
+__device__ __forceinline__ int wave_allmin_i32(int x) {
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) {
+    const int o = (int)lane_xor_sw((u32)x, s);
+    x = o < x ? o : x;
+  }
+  return x;
+}
+
 template <class C>
 __device__ inline C wave_sort64_desc(C v, int lane) {
 #pragma unroll
   for (int size = 2; size <= 64; size <<= 1) {
 #pragma unroll
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      const C o = wave_xchg(v, lane ^ stride);
+      const C o = wave_xchg_xor(v, stride);
       const bool keep_better = (((lane & size) == 0) == ((lane & stride) == 0));
       const bool mine_better = better(v, o);
       v = (keep_better == mine_better) ? v : o;
@@ -239,7 +360,7 @@ __device__ inline int wave_select_small(const C (&keys)[V], int k, C* scratch /*
   for (int v = 0; v < V; ++v)
     if (better(keys[v], lbest)) lbest = keys[v];
   const C sorted_best = wave_sort64_desc(lbest, lane);
-  const C T = wave_xchg(sorted_best, k - 1 < 63 ? k - 1 : 63);  // k-th local best (pad if fewer)
+  const C T = wave_bcast(sorted_best, k - 1 < 63 ? k - 1 : 63);  // k-th local best (pad if fewer)
   int cnt = 0;
 #pragma unroll
   for (int v = 0; v < V; ++v) {

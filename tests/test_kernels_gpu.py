@@ -99,6 +99,31 @@ def test_dense_fuzz_shapes(nat):
         check_dense(nat, X, Q, k)
 
 
+@pytest.mark.parametrize("orient", ["t", "n"])
+def test_dense_batched_both_orientations(nat, orient, monkeypatch):
+    """The batched form has two decompositions (chunk tiles or query tiles held in LDS; the
+    planner picks by balance).  Pin each in turn over shapes with partial tiles on both sides."""
+    monkeypatch.setenv("AMDR_DENSE_ORIENT", orient)
+    rng = np.random.default_rng(77)
+    for n, d, nq, k in [(591, 768, 2500, 10), (100, 64, 700, 5), (1999, 384, 1030, 20), (33, 1024, 300, 50),
+                        (40, 832, 333, 7), (1, 128, 40, 3), (65, 192, 5, 80), (4097, 256, 95, 10)]:
+        check_dense(nat, unit_rows(rng, n, d), unit_rows(rng, nq, d), k)
+
+
+def test_dense_orientations_agree_bitwise(nat, monkeypatch):
+    """Both decompositions run the same k-ordered fp32 MFMA chain per (query, row): identical bits."""
+    rng = np.random.default_rng(78)
+    X, Q = unit_rows(rng, 591, 768), unit_rows(rng, 1500, 768)
+    out = {}
+    for orient in ("n", "t"):
+        monkeypatch.setenv("AMDR_DENSE_ORIENT", orient)
+        idx = nat.DenseIndex(X)
+        out[orient] = idx.search(Q, 10)
+        idx.close()
+    assert np.array_equal(out["n"][1], out["t"][1])
+    assert np.array_equal(out["n"][0], out["t"][0])
+
+
 def test_dense_golden_fixture(nat):
     """Seeded fixture of SURVEY.md §8c(3): X[4096,768], Q[16,768], rng(0)."""
     g = np.load(str(__import__("conftest").GOLDEN / "dense_flatip_golden.npz"))
