@@ -12,8 +12,8 @@
 //   B (2 x 32 rows)   : lane (j = l&31, h)        <- X[r0+j][k]   (HBM -> registers -> LDS -> registers)
 // X is fetched with fully coalesced 16-B/lane loads (8 rows x 128 B per wave
 // instruction, each byte of X read from HBM exactly once), parked in a wave-private,
-// XOR-swizzled, double-buffered 4-KiB LDS stage and read back row-per-lane as the MFMA
-// wants it; two 32-float chunks per wave (64 KiB per CU with 8 waves) are always in flight.
+// XOR-swizzled 4-KiB LDS stage and read back row-per-lane as the MFMA wants it; four
+// 32-float chunks per wave (128 KiB per CU with 8 waves) are always in flight in registers.
 // The k order inside a chunk is permuted (lane half h takes slots 4h..4h+3); A and B use
 // the same permutation, which a dot product cannot see.  C[query][row] comes
 // back with the row on the lane, so each accumulator register is stored as two
@@ -33,7 +33,14 @@ typedef float v4f __attribute__((ext_vector_type(4)));  // native vector: stays 
 
 constexpr int kBW = 4;          // waves per block
 constexpr int kKC = 32;         // floats of every row per staged chunk (128 B = 8 slots of 16 B)
-constexpr int kStageBytes = 32 * kKC * 4;  // 4 KiB: one 32-row x 32-float chunk; each wave owns TWO (double buffer)
+constexpr int kStageBytes = 32 * kKC * 4;  // 4 KiB: one 32-row x 32-float chunk
+#ifndef AMDR_STAGE_BUFS
+#define AMDR_STAGE_BUFS 1
+#endif
+// LDS stages per wave.  One is enough: the LDS unit serves a wave's operations in order, so the
+// ds_writes of chunk c+2 cannot overtake the fragment reads of chunk c+1 issued before them, and
+// those reads land in registers (FX/FQ) a whole chunk of MFMAs before they are used.
+constexpr int kStageBufs = AMDR_STAGE_BUFS;
 constexpr int kPieces = kStageBytes / 1024;  // 1-KiB wave loads per chunk (4): 8 rows x 128 B each
 constexpr int kDepth = 4;                      // chunks in flight from HBM per wave (16 KiB)
 constexpr int kFr = kKC / 8;                  // float4 fragments per lane and chunk (4): its half of the 8 slots
@@ -97,7 +104,7 @@ __device__ __forceinline__ int stage_off(int row, int slot) { return row * 128 +
 #endif
 
 // grid: (x = row slabs, y = 32-query tiles).
-// LDS: Q tile row-major [32][d/4] float4, slots XOR-swizzled per row (d*128 B) + per wave two private 4-KiB chunk stages.
+// LDS: Q tile row-major [32][d/4] float4, slots XOR-swizzled per row (d*128 B) + per wave one private 4-KiB chunk stage.
 //
 // TR = true swaps the roles (the MFMA is symmetric in its two operands): the caller passes
 // the QUERY matrix as the streamed operand X and the CHUNK matrix as the tiled operand Q, so
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
   static_assert(d % kKC == 0, "dim must be a multiple of 64");
   const v4f* qsv = reinterpret_cast<const v4f*>(smem);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned char* stage = smem + (size_t)d * 128 + (size_t)wave * 2 * kStageBytes;
+  unsigned char* stage = smem + (size_t)d * 128 + (size_t)wave * kStageBufs * kStageBytes;
   const int i = lane & 31, h = lane >> 5;
   const int q0 = blockIdx.y * 32;
 
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
       // c+1+kDepth (4 loads) and its fragment reads (8 ds_read).  The LDS unit serves a wave's
       // operations in order and the compiler keeps the may-alias write->read order on `stage`.
       if (c + 1 < NCH) {
-        unsigned char* st_n = stage + ((c + 1) & 1) * kStageBytes;
+        unsigned char* st_n = stage + ((c + 1) % kStageBufs) * kStageBytes;
         AMDR_STAGE_CHUNK(st_n, G[(c + 1) % kDepth])
         if (c + 1 + kDepth < NCH) {
 #pragma unroll
@@ -223,16 +230,17 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
       }
     } else {
       // lane i holds streamed row r0+i (a query) against the 16 tiled rows qrow(g, h) (chunks):
-      // park the 32x32 tile in the wave's stages as T[i][qrow] (row pitch 33 floats: 4 224 B of
-      // the 8 KiB), read it back with the chunk index on the lane, store 2 x 128 B per instruction.
+      // park the 32x32 tile in the wave's stage as T[i][qrow ^ i] (4 KiB, column index XOR row:
+      // conflict-free both ways), read it back with the chunk index on the lane, store
+      // 2 x 128 B per instruction.
       float* tf = reinterpret_cast<float*>(stage);
 #pragma unroll
-      for (int g = 0; g < 16; ++g) tf[i * 33 + (g & 3) + 8 * (g >> 2) + 4 * h] = acc[g];
+      for (int g = 0; g < 16; ++g) tf[i * 32 + (((g & 3) + 8 * (g >> 2) + 4 * h) ^ i)] = acc[g];
       wave_lds_fence();
 #pragma unroll
       for (int p = 0; p < 16; ++p) {
         const int rr = 2 * p + h;
-        const float v = tf[rr * 33 + i];
+        const float v = tf[rr * 32 + (i ^ rr)];
         if (r0 + rr < row_hi && q0 + i < nq) S[(size_t)(r0 + rr) * nq + q0 + i] = v;
       }
       wave_lds_fence();  // the next tile's first chunk is staged over T
@@ -302,10 +310,10 @@ __global__ __launch_bounds__(WAVES * 64) void scores_slab_topk_kernel(const floa
 bool dense_mfma_supported(int d) { return d >= 64 && d <= 1024 && d % 64 == 0; }
 
 // Plan shared by reserve and launch.
-// waves per block: each needs 2 x 4 KiB of stage beside the d*128-byte Q tile in 160 KiB of LDS
-static int scores_waves(int d) {
-  int w = (int)((160 * 1024 - (long)d * 128) / (2 * kStageBytes));
-  return w > 8 ? 8 : w;  // d <= 768: 8 waves (two per SIMD); d = 1024: 4
+// waves per block: each needs kStageBufs x 4 KiB of stage beside the d*128-byte LDS tile in 160 KiB of LDS
+static constexpr int scores_waves(int d) {
+  int w = (int)((160 * 1024 - (long)d * 128) / (kStageBufs * kStageBytes));
+  return w > 8 ? 8 : w;  // two waves per SIMD wherever the LDS tile leaves room (every d <= 1024 with one stage)
 }
 
 // One orientation of the tile product: `tiles` 32-row tiles of the streamed operand are cut
@@ -363,7 +371,7 @@ void dense_mfma_plan(long n, int d, int nq, int k, DenseMfmaPlan* p) {
     p->grid_y = p->q_tiles;
   }
   if (p->grid_x < 1) p->grid_x = 1;
-  p->lds_scores = (size_t)d * 32 * sizeof(float) + (size_t)kBW * 2 * kStageBytes;
+  p->lds_scores = (size_t)d * 32 * sizeof(float) + (size_t)kBW * kStageBufs * kStageBytes;
   p->waves = kBW;
   // top-k pass: slabs of >= 16 Ki rows, enough blocks to fill the chip
   long sl = (256L * 8 + nq - 1) / nq;
@@ -385,7 +393,7 @@ static void launch_scores(const DenseMfmaPlan& p, const float* X, long n, const 
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)dense_mfma_scores_kernel<D8, WAVES, TR>,
                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                              D8 * 8 * 32 * (int)sizeof(float) + WAVES * 2 * kStageBytes);
+                              D8 * 8 * 32 * (int)sizeof(float) + WAVES * kStageBufs * kStageBytes);
     attr_done = true;
   }
   // TR: the query matrix is the streamed operand, the chunk matrix the tiled one
@@ -400,16 +408,16 @@ static void launch_scores(const DenseMfmaPlan& p, const float* X, long n, const 
 int dense_mfma_launch_scores(const DenseMfmaPlan& p, const float* X, long n, int d, const float* Q, int nq, float* S,
                              hipStream_t st) {
   switch (d) {
-#define AMDR_CASE(D, W)                                              \
-  case D:                                                            \
-    if (p.transposed)                                                \
-      launch_scores<D / 8, W, true>(p, X, n, Q, nq, S, st);          \
-    else                                                             \
-      launch_scores<D / 8, W, false>(p, X, n, Q, nq, S, st);         \
+#define AMDR_CASE(D)                                                          \
+  case D:                                                                     \
+    if (p.transposed)                                                         \
+      launch_scores<D / 8, scores_waves(D), true>(p, X, n, Q, nq, S, st);     \
+    else                                                                      \
+      launch_scores<D / 8, scores_waves(D), false>(p, X, n, Q, nq, S, st);    \
     break;
-    AMDR_CASE(64, 8) AMDR_CASE(128, 8) AMDR_CASE(192, 8) AMDR_CASE(256, 8) AMDR_CASE(320, 8) AMDR_CASE(384, 8)
-    AMDR_CASE(448, 8) AMDR_CASE(512, 8) AMDR_CASE(576, 8) AMDR_CASE(640, 8) AMDR_CASE(704, 8) AMDR_CASE(768, 8)
-    AMDR_CASE(832, 7) AMDR_CASE(896, 6) AMDR_CASE(960, 5) AMDR_CASE(1024, 4)
+    AMDR_CASE(64) AMDR_CASE(128) AMDR_CASE(192) AMDR_CASE(256) AMDR_CASE(320) AMDR_CASE(384)
+    AMDR_CASE(448) AMDR_CASE(512) AMDR_CASE(576) AMDR_CASE(640) AMDR_CASE(704) AMDR_CASE(768)
+    AMDR_CASE(832) AMDR_CASE(896) AMDR_CASE(960) AMDR_CASE(1024)
 #undef AMDR_CASE
     default: return fail(AMDR_EINVAL, "dense (batched): unsupported dim %d", d);
   }
