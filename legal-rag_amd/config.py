@@ -15,7 +15,7 @@ from __future__ import annotations
 import os
 from dataclasses import dataclass, field, replace
 from pathlib import Path
-from typing import Optional
+from typing import Dict, List, Optional
 
 
 @dataclass
@@ -34,9 +34,15 @@ class RetrievalConfig:
     hnsw_ef_search: int = 512
     # sparse
     bm25_index_file: str = "index/bm25.pkl"
-    # graph (channel out of scope; flag honoured as "off")
-    enable_graph: bool = False
+    # graph (config.py:74-88; the channel runs only for GRAPH_AUGMENTED routing decisions and
+    # switches itself off when the graph file is missing)
+    enable_graph: bool = True
     graph_seed_k: int = 30
+    graph_walk_depths: Dict[str, int] = field(default_factory=lambda: {
+        "defined_by": 4, "defines_term": 3, "cite": 1, "cited_by": 1, "prev": 2, "next": 2, "default": 2})
+    graph_limit: int = 800
+    graph_weight: float = 0.2
+    graph_rel_types: Optional[List[str]] = None
     # control
     top_k: int = 10
     bm25_weight: float = 0.4
@@ -77,6 +83,8 @@ class PathsConfig:
     processed_dir: str = "data/processed"
     index_dir: str = "data/index"
     law_jsonl: str = "data/processed/law_zh.jsonl"
+    graph_dir: str = "data/graph"
+    law_graph_jsonl: str = "data/graph/law_graph_zh.jsonl"
 
 
 def active_index_dir(index_root: Path, version: Optional[str] = None) -> Path:
@@ -123,5 +131,6 @@ class AppConfig:
             r.embedding_model = r.embedding_model_zh
             r.colbert_index_name = r.colbert_index_name_zh
         p = PathsConfig(data_dir=str(data_dir), processed_dir=str(processed), index_dir=str(index_root),
-                        law_jsonl=str(processed / f"law_{lang_key}.jsonl"))
+                        law_jsonl=str(processed / f"law_{lang_key}.jsonl"), graph_dir=str(data_dir / "graph"),
+                        law_graph_jsonl=str(data_dir / "graph" / f"law_graph_{lang_key}.jsonl"))
         return AppConfig(paths=p, retrieval=r)

@@ -16,8 +16,8 @@ Differences from the reference, all deliberate:
   * exactly tied fused scores keep first-appearance order (dense list, then
     bm25, then colbert) instead of Python set-iteration order
     (hybrid_retriever.py:460,484,526 — PYTHONHASHSEED dependent there);
-  * the graph channel is out of scope: `.graph` is always None,
-    `search_graph` returns [] and a GRAPH_AUGMENTED decision degrades to RAG.
+  * the graph channel (graph_retriever.py) rescores the walked articles with a row
+    gather + dot on the resident chunk matrix instead of re-embedding their text.
 """
 from __future__ import annotations
 
@@ -35,6 +35,7 @@ from ..schemas import RetrievalHit
 from .bm25_retriever import BM25Retriever
 from .colbert_retriever import ColBERTRetriever
 from .dense_retriever import DenseRetriever
+from .graph_retriever import GraphRetriever
 from .rerankers import RerankerFactory, _to_doc_text
 
 logger = logging.getLogger("legalrag.retrieval.hybrid_retriever")
@@ -120,7 +121,12 @@ class HybridRetriever:
                 print("[HybridRetriever] ColBERT init failed:", repr(e))
                 traceback.print_exc()
                 self.colbert = None
-        self.graph = None  # out of scope for this build (module docstring)
+        self.graph = None
+        if getattr(self.cfg.retrieval, "enable_graph", False):
+            try:
+                self.graph = GraphRetriever(self.cfg)
+            except Exception:  # noqa: BLE001 - no graph file / no index: channel off, as the reference (:171-177)
+                self.graph = None
 
     # ------------------------------------------------------------------ knobs
     def _knobs(self) -> Dict[str, Any]:
@@ -186,7 +192,28 @@ class HybridRetriever:
 
     def search_graph(self, question: str, top_k: int = 10, *, decision: Any = None,
                      seeds: Optional[List[RetrievalHit]] = None) -> List[RetrievalHit]:
-        return []
+        """Graph hits for the seeds (hybrid_retriever.py:247-277): without seeds, the three
+        channels' own top graph_seed_k each; hits come back re-sorted, renumbered, relabelled
+        source="retriever" with channel ["graph"]; any failure -> []."""
+        top_k = max(1, int(top_k))
+        if self.graph is None:
+            return []
+        if seeds is None:
+            seed_n = int(getattr(self.cfg.retrieval, "graph_seed_k", max(10, top_k * 3)))
+            seeds = (self.search_dense(question, seed_n)[:seed_n] + self.search_bm25(question, seed_n)[:seed_n]
+                     + self.search_colbert(question, seed_n)[:seed_n])
+        try:
+            hits = self.graph.search(question, seeds, decision=decision, top_k=top_k)
+            hits.sort(key=lambda h: float(h.score), reverse=True)
+            for i, h in enumerate(hits, start=1):
+                h.rank = i
+                h.source = "retriever"
+                sb = h.score_breakdown or {}
+                sb["channel"] = _as_channel_list(sb.get("channel")) or ["graph"]
+                h.score_breakdown = sb
+            return hits
+        except Exception:  # noqa: BLE001
+            return []
 
     # -------------------------------------------------------------- fusion
     def _fuse(self, *, dense_hits: List[RetrievalHit], bm25_hits: List[RetrievalHit],
@@ -277,11 +304,11 @@ class HybridRetriever:
 
         t_graph = None
         if getattr(rcfg, "enable_graph", False) and _is_graph_mode(getattr(decision, "mode", None)):
-            # graph channel not built: the reference's `seeds + graph_hits` degenerates to the seeds
+            # the fused list is cut to the seeds even when the graph channel is off (:317-320)
             seed_n = int(getattr(rcfg, "graph_seed_k", max(10, top_k * 3)))
-            if self.graph is not None:
-                fused = fused[:seed_n] + self.search_graph(question, eff_top_k, decision=decision, seeds=fused[:seed_n])
-                t_graph = time.time()
+            seeds = fused[:seed_n]
+            fused = seeds + self.search_graph(question, eff_top_k, decision=decision, seeds=seeds)
+            t_graph = time.time()
 
         t_rerank = None
         if getattr(rcfg, "enable_rerank", False):

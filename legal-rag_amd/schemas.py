@@ -38,3 +38,29 @@ class RetrievalHit(BaseModel):
     relations: Optional[List[str]] = None
     seed_article_id: Optional[str] = None
     score_breakdown: Optional[Dict[str, Any]] = None
+
+
+class Neighbor(BaseModel):
+    """Directed edge of the law graph (legalrag/schemas.py:129-134)."""
+    article_id: str
+    relation: str = "neighbor"
+    conf: float = 1.0
+    evidence: Optional[Dict[str, Any]] = None
+
+
+class LawNode(BaseModel):
+    """Node of the law graph (legalrag/schemas.py:136-150).  The last three fields are filled
+    per query on a COPY of the stored node by LawGraphStore.walk; `relations` is declared a
+    string upstream but walk stores a one-element list in it (pydantic does not validate
+    assignments), so it is typed loosely here."""
+    article_id: str
+    article_no: str = ""
+    law_name: Optional[str] = None
+    title: Optional[str] = None
+    chapter: Optional[str] = None
+    section: Optional[str] = None
+    neighbors: List[Neighbor] = []
+    meta: Dict[str, Any] = {}
+    graph_depth: Optional[int] = None
+    graph_parent: Optional[str] = None
+    relations: Optional[Any] = None

@@ -112,6 +112,34 @@ def test_product_search_matches_reference_vectors(case, monkeypatch):
         assert scores_g == scores_e
 
 
+GRAPH = load_golden("graph_golden.json")
+
+
+@pytest.mark.parametrize("case", GRAPH["hybrid"], ids=[c["name"] for c in GRAPH["hybrid"]])
+def test_product_search_with_routing_decision_matches_reference(case, monkeypatch):
+    """HybridRetriever.search under a routing decision (graph channel on / off / not selected):
+    seeds cut, graph hits appended, rerank, dedup — against the reference's own search()."""
+    import types
+    from test_graph import GRAPH_FILE, HostStore
+    from legal_rag_amd.retrieval import hybrid_retriever as hr
+    from legal_rag_amd.retrieval.graph_retriever import GraphRetriever
+    from legal_rag_amd.retrieval.graph_store import LawGraphStore
+    store = HostStore()
+    by = {c.article_id: c for c in store.chunks}
+    r = bare_retriever(**case["knobs"])
+    r.cfg.paths.law_graph_jsonl = str(GRAPH_FILE)
+    r.dense = FakeDense(case["dense"], by)
+    r.bm25 = FakePairs(case["bm25"], by)
+    r.colbert = FakePairs(case["colbert"], by) if case["colbert"] else None
+    if case["with_graph"]:
+        r.graph = GraphRetriever(r.cfg, graph=LawGraphStore(r.cfg), store=store)
+    fake = FakeReranker(case["ce_raw_by_id"])
+    monkeypatch.setattr(hr.RerankerFactory, "create", lambda self, top_k: fake)
+    out = r.search("the question", llm=None, top_k=case["top_k"], decision=types.SimpleNamespace(mode=case["mode"]))
+    assert_hits_equal_mod_ties([dump(h) for h in out], case["expected"], float_tol=1e-6)
+    assert [h.chunk.source for h in out] == [e["chunk_source"] for e in case["expected"]]
+
+
 # ---------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def ucc_index(tmp_path_factory):
