@@ -355,7 +355,7 @@ def main():
         cnt = res.count.cpu().numpy()
         rec = hybrid_recall(ids[:nq0], cnt[:nq0], W["chunks"], W["queries"], K)
         # ---- single-query latency through the same kernels (B = 1) ----------
-        lat_us = lat_p50 = lat_p99 = None
+        lat_us = lat_p50 = lat_p99 = lat_graph_p50 = lat_graph_p99 = None
         if rank == 0:
             q1 = q_emb[:1].contiguous()
             t1 = q_terms[: int(q_ptr_h[1])].contiguous() if q_ptr_h[1] > 0 else q_terms[:1]
@@ -372,6 +372,19 @@ def main():
             lat.sort()
             lat_us = sum(lat) / len(lat)
             lat_p50, lat_p99 = lat[len(lat) // 2], lat[int(len(lat) * 0.99)]
+            # the same single-query step recorded once into a hipGraph and replayed (one launch per query)
+            graph, _gres = eng.capture(params, K, q_emb=q1, q_terms=t1, q_ptr=p1)
+            for _ in range(20):
+                graph.replay()
+            torch.cuda.synchronize()
+            glat = []
+            for _ in range(300):
+                tt = time.perf_counter()
+                graph.replay()
+                torch.cuda.synchronize()
+                glat.append((time.perf_counter() - tt) * 1e6)
+            glat.sort()
+            lat_graph_p50, lat_graph_p99 = glat[len(glat) // 2], glat[int(len(glat) * 0.99)]
 
         rows_local = hi - lo
         d = W["X"].shape[1]
@@ -403,6 +416,7 @@ def main():
                        "top_k": K, "shard": shard, "fusion": "rrf_norm_blend w=0.6/0.4 alpha=0.5 rrf_k=60 "
                        "min_final=0.2"},
             "recall_at_10": rec, "latency_b1_us": lat_us, "latency_b1_p50_us": lat_p50, "latency_b1_p99_us": lat_p99,
+            "latency_b1_graph_p50_us": lat_graph_p50, "latency_b1_graph_p99_us": lat_graph_p99,
             "roofline": roofline,
         }
         if rank == 0:

@@ -47,6 +47,69 @@ __device__ __forceinline__ long long chan_uid(const ChanIn& c, int qi, int j) {
   return id;
 }
 
+// Everything _fuse reports for one candidate (hybrid_retriever.py:389-551), operand for operand
+// in the reference's order; shared by the one-query-per-wave kernel and the packed one.
+struct FuseCtx {
+  double rmn, rmx;  // min / max of the RRF totals over the union
+  bool rdeg, wrrf;
+  double w[3], lo[3], hi[3];  // channel weight, min and max of the channel's scores
+};
+template <class ScoreAt>
+__device__ __forceinline__ void fuse_eval(const amdr_fuse_params_t& P, const FuseCtx& X, double t, const int (&pos)[3],
+                                          ScoreAt&& score_at, double (&val)[AMDR_FUSE_NVALS], int& mk) {
+  const double rrf_norm = X.rdeg ? 0.0 : (t - X.rmn) / (X.rmx - X.rmn);
+  double nrm[3], raw[3], wt[3];
+  mk = 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int p = pos[c];
+    nrm[c] = 0.0;
+    raw[c] = 0.0;
+    if (p >= 0) {
+      mk |= (1 << c);
+      const double s = score_at(c, p);
+      nrm[c] = (X.hi[c] - X.lo[c] < 1e-12) ? 0.0 : (s - X.lo[c]) / (X.hi[c] - X.lo[c]);
+      const double wc = X.wrrf ? X.w[c] : 1.0;
+      raw[c] = wc * (1.0 / (double)(P.rrf_k + p + 1));
+    }
+    wt[c] = X.w[c] * nrm[c];
+  }
+  const double wsum = (wt[0] + wt[1]) + wt[2];
+  double score, con[3] = {0.0, 0.0, 0.0};
+  if (P.method == AMDR_FUSE_WEIGHTED_SUM) {
+    score = wsum;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) con[c] = wt[c];
+  } else if (P.method == AMDR_FUSE_RRF || P.method == AMDR_FUSE_WRRF) {
+    score = rrf_norm;
+    const double mass = score;
+    if (!(mass <= 0.0 || t <= 1e-18)) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        if (pos[c] >= 0) con[c] = mass * raw[c] / t;
+    }
+  } else {
+    score = P.alpha * rrf_norm + (1.0 - P.alpha) * wsum;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) con[c] = 0.0 + (1.0 - P.alpha) * wt[c];
+    const double mass = P.alpha * rrf_norm;
+    if (!(mass <= 0.0 || t <= 1e-18)) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        if (pos[c] >= 0) con[c] = con[c] + mass * raw[c] / t;
+    }
+  }
+  val[AMDR_FV_SCORE] = score;
+  val[AMDR_FV_RRF_NORM] = rrf_norm;
+  val[AMDR_FV_WSUM] = wsum;
+  val[AMDR_FV_NORM_DENSE] = nrm[0];
+  val[AMDR_FV_NORM_BM25] = nrm[1];
+  val[AMDR_FV_NORM_COLBERT] = nrm[2];
+  val[AMDR_FV_CONTRIB_DENSE] = con[0];
+  val[AMDR_FV_CONTRIB_BM25] = con[1];
+  val[AMDR_FV_CONTRIB_COLBERT] = con[2];
+}
+
 // block = 64 threads (one wave); grid = nq
 __global__ __launch_bounds__(64) void fuse_kernel(amdr_fuse_params_t P, ChanIn c0, ChanIn c1, ChanIn c2, int max_out,
                                                   long long* __restrict__ out_ids, double* __restrict__ out_vals,
@@ -138,61 +201,22 @@ __global__ __launch_bounds__(64) void fuse_kernel(amdr_fuse_params_t P, ChanIn c
   rmx = wave_max(rmx);
   const bool rdeg = (rmx - rmn < 1e-12);
 
-  // all values of candidate u; evaluated twice (score pass, output pass) so that
-  // nothing but the score has to live across the rank computation
+  // all values of candidate u (fuse_eval); the long-list path evaluates twice (score pass,
+  // output pass) so that nothing but the score has to live across the rank computation
+  FuseCtx X;
+  X.rmn = rmn;
+  X.rmx = rmx;
+  X.rdeg = rdeg;
+  X.wrrf = wrrf;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    X.w[c] = w[c];
+    X.lo[c] = lo[c];
+    X.hi[c] = hi[c];
+  }
   auto eval = [&](int u, double (&val)[AMDR_FUSE_NVALS], int& mk) {
-    const double t = tot[u];
-    const double rrf_norm = rdeg ? 0.0 : (t - rmn) / (rmx - rmn);
-    double nrm[3], raw[3], wt[3];
-    mk = 0;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      int p = pos[c][u];
-      nrm[c] = 0.0;
-      raw[c] = 0.0;
-      if (p >= 0) {
-        mk |= (1 << c);
-        double s = chan_score(ch[c], qi, p);
-        nrm[c] = (hi[c] - lo[c] < 1e-12) ? 0.0 : (s - lo[c]) / (hi[c] - lo[c]);
-        double wc = wrrf ? w[c] : 1.0;
-        raw[c] = wc * (1.0 / (double)(P.rrf_k + p + 1));
-      }
-      wt[c] = w[c] * nrm[c];
-    }
-    const double wsum = (wt[0] + wt[1]) + wt[2];
-    double score, con[3] = {0.0, 0.0, 0.0};
-    if (P.method == AMDR_FUSE_WEIGHTED_SUM) {
-      score = wsum;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) con[c] = wt[c];
-    } else if (P.method == AMDR_FUSE_RRF || P.method == AMDR_FUSE_WRRF) {
-      score = rrf_norm;
-      const double mass = score;
-      if (!(mass <= 0.0 || t <= 1e-18)) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-          if (pos[c][u] >= 0) con[c] = mass * raw[c] / t;
-      }
-    } else {
-      score = P.alpha * rrf_norm + (1.0 - P.alpha) * wsum;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) con[c] = 0.0 + (1.0 - P.alpha) * wt[c];
-      const double mass = P.alpha * rrf_norm;
-      if (!(mass <= 0.0 || t <= 1e-18)) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-          if (pos[c][u] >= 0) con[c] = con[c] + mass * raw[c] / t;
-      }
-    }
-    val[AMDR_FV_SCORE] = score;
-    val[AMDR_FV_RRF_NORM] = rrf_norm;
-    val[AMDR_FV_WSUM] = wsum;
-    val[AMDR_FV_NORM_DENSE] = nrm[0];
-    val[AMDR_FV_NORM_BM25] = nrm[1];
-    val[AMDR_FV_NORM_COLBERT] = nrm[2];
-    val[AMDR_FV_CONTRIB_DENSE] = con[0];
-    val[AMDR_FV_CONTRIB_BM25] = con[1];
-    val[AMDR_FV_CONTRIB_COLBERT] = con[2];
+    const int pp[3] = {pos[0][u], pos[1][u], pos[2][u]};
+    fuse_eval(P, X, tot[u], pp, [&](int c, int p) { return chan_score(ch[c], qi, p); }, val, mk);
   };
 
   // ---- score, stable descending rank, filter, scatter ---------------------
@@ -254,6 +278,160 @@ __global__ __launch_bounds__(64) void fuse_kernel(amdr_fuse_params_t P, ChanIn c
     for (int x = 0; x < AMDR_FUSE_NVALS; ++x) out_vals[(obase + r) * AMDR_FUSE_NVALS + x] = 0.0;
   }
   if (lane == 0) out_count[qi] = kept;
+}
+
+
+// Packed form for the serving shape: when all candidates of a query fit in W lanes (max_out
+// <= W; top-10 of two or three channels -> W = 32), a wave fuses 64 / W queries side by side,
+// one candidate per lane.  Same arithmetic as fuse_kernel (fuse_eval), same outputs; the
+// reductions run inside the W-lane group and the ballots are cut to the group's bits.  The
+// kernel is bound by vector instructions issued per wave (fp64 divisions), not by data, so
+// halving the waves halves its time.
+template <int W>
+__global__ __launch_bounds__(64) void fuse_packed_kernel(amdr_fuse_params_t P, ChanIn c0, ChanIn c1, ChanIn c2, int nq,
+                                                         int max_out, long long* __restrict__ out_ids,
+                                                         double* __restrict__ out_vals, int* __restrict__ out_mask,
+                                                         int* __restrict__ out_count) {
+  constexpr int G = 64 / W;  // queries per wave
+  __shared__ long long s_uid[G][W];
+  __shared__ double s_sc[G][W];
+  __shared__ double s_chs[G][3][W];  // channel scores by list position
+  __shared__ int s_pos[G][3][W];
+  const int lane = threadIdx.x, seg = lane / W, sl = lane % W;
+  const int qi = blockIdx.x * G + seg;
+  const bool live = qi < nq;
+  const ChanIn ch[3] = {c0, c1, c2};
+  const double w[3] = {P.w_dense, P.w_bm25, P.w_colbert};
+  const unsigned long long seg_bits = (W == 64) ? ~0ull : (((1ull << (W & 63)) - 1ull) << (seg * W));
+  long long* uid = s_uid[seg];
+  double* sc = s_sc[seg];
+
+  // ---- per channel: valid prefix length, min / max, ids and scores -----------------------
+  int n[3];
+  double lo[3], hi[3];
+  long long my_uid[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int j = sl;
+    bool has = live && j < ch[c].k;
+    long long id = -1;
+    if (has) id = ch[c].ids[(size_t)qi * ch[c].k + j];
+    has = has && id >= 0;
+    double s = 0.0;
+    if (has) {
+      s = chan_score(ch[c], qi, j);
+      if (ch[c].row2uid) id = ch[c].row2uid[id];
+    }
+    my_uid[c] = has ? id : -1;
+    s_chs[seg][c][sl] = s;
+    n[c] = seg_allsum_i32<W>(has ? 1 : 0);
+    lo[c] = seg_allmin_f64<W>(has ? s : (double)INFINITY);
+    hi[c] = seg_allmax_f64<W>(has ? s : -(double)INFINITY);
+  }
+
+  // ---- union of ids in first-appearance order ----------------------------------------------
+  int U = 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int U0 = U;
+    const bool v = sl < n[c];  // valid entries form a prefix (-1 padding at the tail)
+    const long long my = my_uid[c];
+    int f = -1;
+    if (v)
+      for (int u = 0; u < U0; ++u)
+        if (uid[u] == my) {
+          f = u;
+          break;
+        }
+    const bool isnew = v && f < 0;
+    const unsigned long long m = __ballot(isnew) & seg_bits;
+    const unsigned long long lt = m & ((1ull << lane) - 1ull);
+    const int idx = isnew ? U + __popcll(lt) : f;
+    if (isnew) {
+      uid[idx] = my;
+      s_pos[seg][0][idx] = -1;
+      s_pos[seg][1][idx] = -1;
+      s_pos[seg][2][idx] = -1;
+    }
+    lds_sync();
+    if (v) s_pos[seg][c][idx] = sl;
+    U += __popcll(m);
+    lds_sync();
+  }
+
+  // ---- RRF totals, their min / max -------------------------------------------------------------
+  const bool wrrf = (P.method == AMDR_FUSE_WRRF);
+  const int u = sl;
+  const bool act = u < U;
+  int pp[3] = {-1, -1, -1};
+  double t = 0.0;
+  if (act) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      pp[c] = s_pos[seg][c][u];
+      if (pp[c] >= 0) {
+        const double wc = wrrf ? w[c] : 1.0;
+        const double v = wc * (1.0 / (double)(P.rrf_k + pp[c] + 1));
+        t = t + v;
+      }
+    }
+  }
+  FuseCtx X;
+  X.rmn = seg_allmin_f64<W>(act ? t : (double)INFINITY);
+  X.rmx = seg_allmax_f64<W>(act ? t : -(double)INFINITY);
+  X.rdeg = (X.rmx - X.rmn < 1e-12);
+  X.wrrf = wrrf;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    X.w[c] = w[c];
+    X.lo[c] = lo[c];
+    X.hi[c] = hi[c];
+  }
+
+  // ---- score, stable descending rank, filter, scatter --------------------------------------------
+  double val[AMDR_FUSE_NVALS];
+  int mk = 0;
+  if (act) {
+    fuse_eval(P, X, t, pp, [&](int c, int p) { return s_chs[seg][c][p]; }, val, mk);
+    sc[u] = val[AMDR_FV_SCORE];
+  }
+  lds_sync();
+  int kept = 0;
+  const size_t obase = (size_t)qi * max_out;
+  if (act) {
+    const double s = val[AMDR_FV_SCORE];
+    int r = 0;
+    for (int v2 = 0; v2 < U; ++v2) {
+      const double o = sc[v2];
+      r += (o > s) || (o == s && v2 < u);
+    }
+    if (s >= P.min_final_score) kept = 1;
+    out_ids[obase + r] = uid[u];
+    out_mask[obase + r] = mk;
+#pragma unroll
+    for (int x = 0; x < AMDR_FUSE_NVALS; ++x) out_vals[(obase + r) * AMDR_FUSE_NVALS + x] = val[x];
+  } else if (live && u < max_out) {  // rows past the union: padding
+    out_ids[obase + u] = -1;
+    out_mask[obase + u] = 0;
+#pragma unroll
+    for (int x = 0; x < AMDR_FUSE_NVALS; ++x) out_vals[(obase + u) * AMDR_FUSE_NVALS + x] = 0.0;
+  }
+  kept = seg_allsum_i32<W>(kept);
+  if (live && sl == 0) out_count[qi] = kept;
+}
+
+// fuse_kernel for long candidate lists, the packed forms when a query fits in 32 or 16 lanes
+static void launch_fuse(const amdr_fuse_params_t& P, const ChanIn& c0, const ChanIn& c1, const ChanIn& c2, int nq,
+                        int max_out, long long* ids, double* vals, int* mask, int* count, hipStream_t st) {
+  if (max_out <= 16)
+    hipLaunchKernelGGL(fuse_packed_kernel<16>, dim3((nq + 3) / 4), dim3(64), 0, st, P, c0, c1, c2, nq, max_out, ids, vals,
+                       mask, count);
+  else if (max_out <= 32)
+    hipLaunchKernelGGL(fuse_packed_kernel<32>, dim3((nq + 1) / 2), dim3(64), 0, st, P, c0, c1, c2, nq, max_out, ids, vals,
+                       mask, count);
+  else
+    hipLaunchKernelGGL(fuse_kernel, dim3(nq), dim3(64), (size_t)max_out * 36, st, P, c0, c1, c2, max_out, ids, vals, mask,
+                       count);
 }
 
 // block = 64 threads; grid = nq.  Dynamic LDS: staging for one query's lists.
@@ -437,9 +615,7 @@ int amdr_fuse_device(const amdr_fuse_params_t* p, int32_t nq, const int64_t* den
   ChanIn c0{(const long long*)dense_ids, dense_scores, (const long long*)dense_row2uid, kd, 0};
   ChanIn c1{(const long long*)bm25_ids, bm25_scores, (const long long*)bm25_row2uid, kb, 1};
   ChanIn c2{(const long long*)colbert_ids, colbert_scores, (const long long*)colbert_row2uid, kc, 0};
-  hipLaunchKernelGGL(fuse_kernel, dim3(nq), dim3(64), (size_t)(kd + kb + kc) * 36, (hipStream_t)stream, *p, c0, c1, c2,
-                     kd + kb + kc,
-                     (long long*)out_ids, out_vals, out_mask, out_count);
+  launch_fuse(*p, c0, c1, c2, nq, kd + kb + kc, (long long*)out_ids, out_vals, out_mask, out_count, (hipStream_t)stream);
   AMDR_HIP(hipGetLastError());
   return AMDR_OK;
 }
@@ -489,8 +665,8 @@ int amdr_fuse(const amdr_fuse_params_t* p, int32_t nq, const int64_t* dense_ids,
   ChanIn c0{(const long long*)(d + o_di), d + o_ds, nullptr, kd, 1};
   ChanIn c1{(const long long*)(d + o_bi), d + o_bs, nullptr, kb, 1};
   ChanIn c2{(const long long*)(d + o_ci), d + o_cs, nullptr, kc, 1};
-  hipLaunchKernelGGL(fuse_kernel, dim3(nq), dim3(64), mo * 36, st, *p, c0, c1, c2, (int)mo, (long long*)(d + o_oi),
-                     (double*)(d + o_ov), (int*)(d + o_om), (int*)(d + o_oc));
+  launch_fuse(*p, c0, c1, c2, nq, (int)mo, (long long*)(d + o_oi), (double*)(d + o_ov), (int*)(d + o_om),
+              (int*)(d + o_oc), st);
   AMDR_HIP(hipGetLastError());
   std::vector<char>& hb = host_block();
   if (hb.size() < total) hb.resize(total);

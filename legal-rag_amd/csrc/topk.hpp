@@ -323,6 +323,28 @@ __device__ __forceinline__ double dpp_f64(double x) {  // every lane valid for t
 AMDR_WAVE_REDUCE_F64(wave_allmax_f64, max_f64_raw)
 AMDR_WAVE_REDUCE_F64(wave_allmin_f64, min_f64_raw)
 #undef AMDR_WAVE_REDUCE_F64
+// The same reductions inside aligned groups of W lanes (W a power of two <= 64): butterfly over
+// the strides below W only.
+template <int W>
+__device__ __forceinline__ double seg_allmax_f64(double x) {
+#pragma unroll
+  for (int s = 1; s < W; s <<= 1)
+    x = max_f64_raw(x, __longlong_as_double((long long)lane_xor_sw((u64)__double_as_longlong(x), s)));
+  return x;
+}
+template <int W>
+__device__ __forceinline__ double seg_allmin_f64(double x) {
+#pragma unroll
+  for (int s = 1; s < W; s <<= 1)
+    x = min_f64_raw(x, __longlong_as_double((long long)lane_xor_sw((u64)__double_as_longlong(x), s)));
+  return x;
+}
+template <int W>
+__device__ __forceinline__ int seg_allsum_i32(int x) {
+#pragma unroll
+  for (int s = 1; s < W; s <<= 1) x += (int)lane_xor_sw((u32)x, s);
+  return x;
+}
 __device__ __forceinline__ int wave_allsum_i32(int x) {
 #pragma unroll
   for (int s = 1; s < 64; s <<= 1) x += (int)lane_xor_sw((u32)x, s);

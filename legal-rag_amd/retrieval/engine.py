@@ -145,3 +145,28 @@ class HybridEngine:
         if c is not None:
             res.colbert_scores, res.colbert_ids = c
         return res
+
+    # -- hipGraph form -----------------------------------------------------------
+    def capture(self, params: _native.FuseParams, k: int, *, q_emb: Optional[torch.Tensor] = None,
+                q_terms: Optional[torch.Tensor] = None, q_ptr: Optional[torch.Tensor] = None,
+                q_tok: Optional[torch.Tensor] = None):
+        """Record one search_batch over the given tensors into a hipGraph.
+
+        Returns (graph, result): `graph.replay()` re-runs the whole step — every kernel of every
+        stage — as ONE launch on the current stream; new queries are written INTO the same input
+        tensors (same nq; the BM25 term array may hold any number of terms up to its length).
+        The "_device" entry points only enqueue and, after reserve(), allocate nothing
+        (include/amdretrieval.h), which is what makes the step capturable.  A step of 4-5 short
+        kernels is launch-bound at small batch: replay removes the per-kernel launch gaps.
+        """
+        nq = (q_emb.shape[0] if q_emb is not None else q_ptr.shape[0] - 1 if q_ptr is not None else q_tok.shape[0])
+        self.reserve(int(nq), int(k), int(q_terms.numel()) if q_terms is not None else 0)
+        side = torch.cuda.Stream(device=self.tdev)
+        side.wait_stream(torch.cuda.current_stream(self.tdev))
+        with torch.cuda.stream(side):  # eager warm-up sizes every lazily grown buffer outside the capture
+            self.search_batch(params, k, q_emb=q_emb, q_terms=q_terms, q_ptr=q_ptr, q_tok=q_tok)
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            res = self.search_batch(params, k, q_emb=q_emb, q_terms=q_terms, q_ptr=q_ptr, q_tok=q_tok)
+        return graph, res

@@ -122,6 +122,16 @@ def test_device_api_is_graph_capturable():
         ref = eng.search_batch(params, k, q_emb=Q, q_terms=qt, q_ptr=qp)  # eager, same inputs
         torch.cuda.synchronize()
         assert torch.equal(got_ids, ref.ids) and torch.equal(got_cnt, ref.count)
+    # the engine's own helper (warm-up + capture), single query
+    q1, t1, p1 = Q[:1].contiguous(), qt[: int(qp_h[1])].contiguous(), qp[:2].contiguous()
+    g1, r1 = eng.capture(params, k, q_emb=q1, q_terms=t1, q_ptr=p1)
+    q1.copy_(Q[5:6])
+    g1.replay()
+    torch.cuda.synchronize()
+    got = r1.dense_ids.clone()
+    ref = eng.search_batch(params, k, q_emb=q1, q_terms=t1, q_ptr=p1)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref.dense_ids)
 
 
 def test_full_size_10m_shard_merge_and_prefix():
