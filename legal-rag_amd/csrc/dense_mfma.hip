@@ -248,6 +248,17 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
   }
 }
 
+template <int V>
+__device__ __forceinline__ int select_row(const float* __restrict__ row, long lo, long hi, int k, int lane, C32* buf) {
+  C32 keys[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const long r = lo + lane + 64 * v;
+    keys[v] = (r < hi) ? C32::make(row[r], (u32)r) : C32::pad();
+  }
+  return wave_select_small<C32, V>(keys, k, buf + 64, lane, buf);
+}
+
 // grid: (x = row slabs, y = queries): top-k of S[q][slab] -> part[slab][q][k], or, when there
 // is a single slab, straight to the final (scores, ids).  WAVES = 1 for short rows.
 template <int WAVES>
@@ -269,14 +280,15 @@ __global__ __launch_bounds__(WAVES * 64) void scores_slab_topk_kernel(const floa
   tk.init(lists + (size_t)wave * cap, cap, k);
   bool done = false;
   if (WAVES == 1 && k <= 64 && hi - lo <= 1024) {
-    // short row: register selector (topk.hpp); scratch = the upper half of the staging buffer
-    C32 keys[16];
-#pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      const long r = lo + lane + 64 * v;
-      keys[v] = (r < hi) ? C32::make(row[r], (u32)r) : C32::pad();
-    }
-    const int got = wave_select_small<C32, 16>(keys, k, tk.buf + 64, lane, tk.buf);
+    // short row: register selector (topk.hpp); scratch = the upper half of the staging buffer.
+    // V = keys per lane, sized to the row (a UCC-en row of 591 scores needs 10, not 16).
+    int got;
+    if (hi - lo <= 256)
+      got = select_row<4>(row, lo, hi, k, lane, tk.buf);
+    else if (hi - lo <= 640)
+      got = select_row<10>(row, lo, hi, k, lane, tk.buf);
+    else
+      got = select_row<16>(row, lo, hi, k, lane, tk.buf);
     if (got >= 0) {
       tk.cnt = got;
       done = true;
