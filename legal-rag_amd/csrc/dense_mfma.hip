@@ -116,8 +116,8 @@ __device__ __forceinline__ int stage_off(int row, int slot) { return row * 128 +
 template <int D8, int WAVES, bool TR>  // D8 = d / 8; WAVES = 8 when the Q tile leaves room for 8 stages (d <= 768)
 __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const float* __restrict__ X, long n,
                                                                  const float* __restrict__ Q, int nq,
-                                                                 long rows_per_block,
-                                                                 float* __restrict__ S /*[nq, n]; TR: [n, nq]*/) {
+                                                                 long rows_per_block, int gx, int gy, long ldS,
+                                                                 float* __restrict__ S /*[queries][ldS]*/) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int d = D8 * 8;
   constexpr int NCH = d / kKC;  // chunks per row: 12 / 24 / 32 (always even: d % 64 == 0)
@@ -126,7 +126,23 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned char* stage = smem + (size_t)d * 128 + (size_t)wave * kStageBufs * kStageBytes;
   const int i = lane & 31, h = lane >> 5;
-  const int q0 = blockIdx.y * 32;
+  // Block id -> (slab bx of the streamed operand, tile by of the LDS operand).  The grid is 1-D and
+  // remapped so that each XCD (blocks with equal id % 8 share one; 8 XCDs, each with its own L2)
+  // owns a CONTIGUOUS range of the slab-major order: the `gy` blocks that stream the same slab
+  // then sit on one XCD and the slab crosses the fabric once, not once per XCD.  (UCC-en step,
+  // PMC: L2-miss reads of this launch 268 MB -> see profiles/; the bijective form of the remap
+  // handles grids that are not a multiple of 8.)
+  int bx, by;
+  {
+    const int nwg = gx * gy, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    // with a single LDS tile (gy == 1) nothing is shared between blocks: plain order (a 10 M-row
+    // scan measured 1 % slower remapped, the UCC-en launch 1.3 % faster and 3.7x less fabric traffic)
+    const int logical = gy == 1 ? bid : (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    bx = logical / gy;
+    by = logical - bx * gy;
+  }
+  const int q0 = by * 32;
 
   // ---- stage the query tile, row-major with a per-row XOR swizzle of the 16-byte slots:
   //   qs[i * d/4 + (k4 ^ (i & 15))] = Q[q0+i][4*k4 .. 4*k4+3]
@@ -163,7 +179,7 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
   }
   __syncthreads();
 
-  const long row_lo = (long)blockIdx.x * rows_per_block;
+  const long row_lo = (long)bx * rows_per_block;
   long row_hi = row_lo + rows_per_block;
   if (row_hi > n) row_hi = n;
   // loader role of this lane inside a 1-KiB piece: 8 rows x 8 slots
@@ -225,7 +241,7 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
           const int qrow = (g & 3) + 8 * (g >> 2) + 4 * h;  // C/D map: row = query within the tile
-          if (q0 + qrow < nq) S[(size_t)(q0 + qrow) * n + r] = acc[g];
+          if (q0 + qrow < nq) S[(size_t)(q0 + qrow) * ldS + r] = acc[g];
         }
       }
     } else {
@@ -241,7 +257,7 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
       for (int p = 0; p < 16; ++p) {
         const int rr = 2 * p + h;
         const float v = tf[rr * 32 + (i ^ rr)];
-        if (r0 + rr < row_hi && q0 + i < nq) S[(size_t)(r0 + rr) * nq + q0 + i] = v;
+        if (r0 + rr < row_hi && q0 + i < nq) S[(size_t)(r0 + rr) * ldS + q0 + i] = v;
       }
       wave_lds_fence();  // the next tile's first chunk is staged over T
     }
@@ -262,7 +278,7 @@ __device__ __forceinline__ int select_row(const float* __restrict__ row, long lo
 // grid: (x = row slabs, y = queries): top-k of S[q][slab] -> part[slab][q][k], or, when there
 // is a single slab, straight to the final (scores, ids).  WAVES = 1 for short rows.
 template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void scores_slab_topk_kernel(const float* __restrict__ S, long n, int nq, int k,
+__global__ __launch_bounds__(WAVES * 64) void scores_slab_topk_kernel(const float* __restrict__ S, long ldS, long n, int nq, int k,
                                                                        int cap, long rows_per_slab,
                                                                        C32* __restrict__ part,
                                                                        float* __restrict__ fin_scores,
@@ -275,7 +291,7 @@ __global__ __launch_bounds__(WAVES * 64) void scores_slab_topk_kernel(const floa
   const long lo = (long)blockIdx.x * rows_per_slab;
   long hi = lo + rows_per_slab;
   if (hi > n) hi = n;
-  const float* row = S + (size_t)qi * n;
+  const float* row = S + (size_t)qi * ldS;
   WaveTopK<C32> tk;
   tk.init(lists + (size_t)wave * cap, cap, k);
   bool done = false;
@@ -394,7 +410,10 @@ void dense_mfma_plan(long n, int d, int nq, int k, DenseMfmaPlan* p) {
   p->slabs = (int)((n + p->rows_per_slab - 1) / p->rows_per_slab);
   if (p->slabs < 1) p->slabs = 1;
   p->cap = topk_cap(k);
-  p->s_bytes = (size_t)nq * (size_t)n * sizeof(float);
+  // rows of S start on 128-byte lines: the 32-column store segments are then whole lines
+  // (unaligned, the transposed launch wrote 1.58x its bytes as partial lines — PMC WRITE_SIZE)
+  p->ld = (n + 31) / 32 * 32;
+  p->s_bytes = (size_t)nq * (size_t)p->ld * sizeof(float);
   p->part_bytes = (size_t)p->slabs * nq * k * sizeof(C32);
 }
 
@@ -410,11 +429,11 @@ static void launch_scores(const DenseMfmaPlan& p, const float* X, long n, const 
   }
   // TR: the query matrix is the streamed operand, the chunk matrix the tiled one
   if (TR)
-    hipLaunchKernelGGL((dense_mfma_scores_kernel<D8, WAVES, true>), dim3(p.grid_x, p.grid_y), dim3(WAVES * 64),
-                       p.lds_scores, st, Q, (long)nq, X, (int)n, p.rows_per_block, S);
+    hipLaunchKernelGGL((dense_mfma_scores_kernel<D8, WAVES, true>), dim3(p.grid_x * p.grid_y), dim3(WAVES * 64),
+                       p.lds_scores, st, Q, (long)nq, X, (int)n, p.rows_per_block, p.grid_x, p.grid_y, p.ld, S);
   else
-    hipLaunchKernelGGL((dense_mfma_scores_kernel<D8, WAVES, false>), dim3(p.grid_x, p.grid_y), dim3(WAVES * 64),
-                       p.lds_scores, st, X, n, Q, nq, p.rows_per_block, S);
+    hipLaunchKernelGGL((dense_mfma_scores_kernel<D8, WAVES, false>), dim3(p.grid_x * p.grid_y), dim3(WAVES * 64),
+                       p.lds_scores, st, X, n, Q, nq, p.rows_per_block, p.grid_x, p.grid_y, p.ld, S);
 }
 
 int dense_mfma_launch_scores(const DenseMfmaPlan& p, const float* X, long n, int d, const float* Q, int nq, float* S,
@@ -442,10 +461,10 @@ int dense_mfma_launch_topk(const DenseMfmaPlan& p, const float* S, long n, int n
   const int waves = p.rows_per_slab <= 1024 ? 1 : kBW;
   size_t lds = (size_t)waves * p.cap * sizeof(C32) + waves * sizeof(int);
   if (waves == 1)
-    hipLaunchKernelGGL(scores_slab_topk_kernel<1>, dim3(p.slabs, nq), dim3(64), lds, st, S, n, nq, k, p.cap,
+    hipLaunchKernelGGL(scores_slab_topk_kernel<1>, dim3(p.slabs, nq), dim3(64), lds, st, S, p.ld, n, nq, k, p.cap,
                        p.rows_per_slab, (C32*)part, fin_scores, (long long*)fin_ids);
   else
-    hipLaunchKernelGGL(scores_slab_topk_kernel<kBW>, dim3(p.slabs, nq), dim3(256), lds, st, S, n, nq, k, p.cap,
+    hipLaunchKernelGGL(scores_slab_topk_kernel<kBW>, dim3(p.slabs, nq), dim3(256), lds, st, S, p.ld, n, nq, k, p.cap,
                        p.rows_per_slab, (C32*)part, fin_scores, (long long*)fin_ids);
   AMDR_HIP(hipGetLastError());
   return AMDR_OK;
