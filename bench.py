@@ -450,6 +450,18 @@ def main():
                 got = [int(x) for x in ids[qi, :min(int(cnt[qi]), K)]]
                 same += int(got == exp[j])
             result["agreement_at_10_vs_oracle"] = same / len(sample)
+            if not with_colbert and shard == "queries":
+                # the evaluation depth of the reference (evaluate_retrieval.py: k = 80), one untimed pass
+                K80 = 80
+                s80 = list(range(0, nq0, max(1, nq0 // 64)))
+                r80 = eng.search_batch(params, K80, q_emb=q_emb[:nq0].contiguous(), q_terms=q_terms[: int(q_ptr_h[nq0])],
+                                       q_ptr=q_ptr[: nq0 + 1].contiguous())
+                ids80, cnt80 = r80.ids.cpu().numpy(), r80.count.cpu().numpy()
+                exp80 = oracle_pipeline(W, s80, K80)
+                ok80 = sum(int([int(x) for x in ids80[qi, :min(int(cnt80[qi]), K80)]] == exp80[j])
+                           for j, qi in enumerate(s80))
+                result["agreement_at_80_vs_oracle"] = ok80 / len(s80)
+                result["recall_at_80"] = hybrid_recall(ids80, cnt80, W["chunks"], W["queries"], K80)
             if not a.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(W, a.cpu_seconds)
         dense.close()
