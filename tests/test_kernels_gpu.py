@@ -260,7 +260,9 @@ def test_bm25_toy_golden(nat):
 
 
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("n_docs,nq,q_len,k", [(591, 3, 32, 10), (40, 2, 32, 80), (200, 2, 17, 5), (3, 1, 32, 10)])
+@pytest.mark.parametrize("n_docs,nq,q_len,k", [(591, 3, 32, 10), (40, 2, 32, 80), (200, 2, 17, 5), (3, 1, 32, 10),
+                                               # >= 8 queries: the blocked form (document tiles shared through LDS)
+                                               (591, 20, 32, 10), (40, 9, 17, 80), (13, 8, 32, 5), (9, 33, 1, 3)])
 def test_maxsim_matches_oracle(nat, n_docs, nq, q_len, k):
     from oracle import maxsim as OM
     rng = np.random.default_rng(n_docs + q_len)
@@ -289,6 +291,22 @@ def test_maxsim_matches_oracle(nat, n_docs, nq, q_len, k):
         sep = np.concatenate([[True], gaps_ok]) & np.concatenate([gaps_ok, [True]])
         assert np.all((got == ei[b, :kk])[sep])
         assert np.all(i[b, kk:] == -1)
+
+
+def test_maxsim_blocked_equals_per_query_bitwise(nat):
+    """Both MaxSim kernels feed the same operands in the same k order to the same MFMA chain:
+    a batch (blocked kernel) returns the bits of its queries run one by one."""
+    rng = np.random.default_rng(4242)
+    n_docs, nq, q_len = 77, 19, 32
+    lens = rng.integers(1, 221, size=n_docs)
+    lens[:6] = [1, 31, 32, 33, 64, 220]
+    doc_ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    D = unit_rows(rng, int(doc_ptr[-1]), 128)
+    Q = unit_rows(rng, nq * q_len, 128).reshape(nq, q_len, 128)
+    idx = nat.MaxSimIndex(D, doc_ptr)
+    batch = idx.scores(Q)
+    single = np.concatenate([idx.scores(Q[b:b + 1]) for b in range(nq)])
+    assert np.array_equal(batch, single)
 
 
 def test_maxsim_rejects_empty_doc(nat):
