@@ -160,6 +160,30 @@ __global__ __launch_bounds__(256) void dense_score_rows_kernel(const float* __re
   if (lane == 63) out[idx] = acc;
 }
 
+// Short corpus, 1-4 queries (the single-query serving call at UCC-en / Civil-Code size): one
+// wave per (query, row) writes S[q][row]; the slab top-k of dense_mfma.hip ranks it.  A row-slab
+// scan with per-wave top-k state is latency-bound here (591 rows = 40 waves walking 15 rows each,
+// then a merge launch: 15.6 + 8.1 us); 591 independent waves finish in one memory round trip.
+__global__ __launch_bounds__(256) void dense_all_scores_kernel(const float* __restrict__ X, long n, int d,
+                                                                const float* __restrict__ Q, int nq, long ldS,
+                                                                float* __restrict__ S) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long idx = (long)blockIdx.x * kWaves + wave;
+  if (idx >= (long)nq * n) return;
+  const int qi = (int)(idx / n);
+  const long r = idx - (long)qi * n;
+  const float* xr = X + (size_t)r * d;
+  const float* qr = Q + (size_t)qi * d;
+  float acc = 0.f;
+  for (int col = lane * 4; col < d; col += 256) {
+    const float4 a = *reinterpret_cast<const float4*>(xr + col);
+    const float4 b = *reinterpret_cast<const float4*>(qr + col);
+    acc = dot4(a, b, acc);
+  }
+  acc = wave_sum_to_lane63(acc);
+  if (lane == 63) S[(size_t)qi * ldS + r] = acc;
+}
+
 // One block per query: stream the per-block lists, keep the best k, decode.
 __global__ __launch_bounds__(256) void dense_merge_kernel(const C32* __restrict__ part, int nparts, int nq, int k,
                                                            int cap, float* __restrict__ out_scores,
@@ -343,6 +367,7 @@ int launch_scan_ch(const ScanPlan& p, const amdr_dense* h, const float* Q, int n
 // Batches of >= kBatchedMin queries take the 32-query-tile MFMA path (dense_mfma.hip);
 // the score matrix workspace is bounded, so very large batches go in chunks of queries.
 constexpr int kBatchedMin = 5;  // measured: from 5 queries up one MFMA tile pass beats the 8-query GEMV pass
+constexpr int64_t kRowWavesMax = 16384;  // rows up to which 1-4 queries take one wave per (query, row)
 constexpr size_t kScoreBytesMax = (size_t)4 << 30;
 
 int batched_chunk(const amdr_dense* h, int nq) {
@@ -353,8 +378,10 @@ int batched_chunk(const amdr_dense* h, int nq) {
   return nq < c ? nq : (int)c;
 }
 
+// Two-pass form: scores S[q][row] (fp32-MFMA tiles for batches, one wave per (query, row) for the
+// 1-4 query call on a short corpus), then slab top-k (+ merge when there are several slabs).
 int run_search_batched(amdr_dense* h, const float* Q_dev, int nq, int k, float* scores_dev, int64_t* ids_dev,
-                       hipStream_t st) {
+                       hipStream_t st, bool row_waves = false) {
   const int chunk = batched_chunk(h, nq);
   DenseMfmaPlan p;
   dense_mfma_plan((long)h->n, h->d, chunk, k, &p);
@@ -366,8 +393,14 @@ int run_search_batched(amdr_dense* h, const float* Q_dev, int nq, int k, float* 
     if (m != chunk) dense_mfma_plan((long)h->n, h->d, m, k, &p);
     const bool prof = h->prof_on && (size_t)(h->prof_used + 2) <= h->prof_ev.size();
     if (prof) AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
-    rc = dense_mfma_launch_scores(p, h->X, (long)h->n, h->d, Q_dev + (size_t)q0 * h->d, m, h->smat.as<float>(), st);
-    if (rc) return rc;
+    if (row_waves) {
+      hipLaunchKernelGGL(dense_all_scores_kernel, dim3(ceil_div((long)m * h->n, kWaves)), dim3(256), 0, st, h->X,
+                         (long)h->n, h->d, Q_dev + (size_t)q0 * h->d, m, p.ld, h->smat.as<float>());
+      AMDR_HIP(hipGetLastError());
+    } else {
+      rc = dense_mfma_launch_scores(p, h->X, (long)h->n, h->d, Q_dev + (size_t)q0 * h->d, m, h->smat.as<float>(), st);
+      if (rc) return rc;
+    }
     if (prof) {
       AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
       h->prof_used += 2;
@@ -391,6 +424,7 @@ int run_search(amdr_dense* h, const float* Q_dev, int nq, int k, float* scores_d
                hipStream_t st) {
   if (nq >= kBatchedMin && h->n > 0 && dense_mfma_supported(h->d))
     return run_search_batched(h, Q_dev, nq, k, scores_dev, ids_dev, st);
+  if (h->n > 0 && h->n <= kRowWavesMax) return run_search_batched(h, Q_dev, nq, k, scores_dev, ids_dev, st, true);
   ScanPlan p;
   make_plan(h->n, h->d, nq, k, &p);
   int rc = h->part.ensure(p.part_bytes);
@@ -533,6 +567,12 @@ int amdr_dense_reserve(amdr_dense_t* h, int32_t nq_max, int32_t k_max) {
   if (nq_max >= kBatchedMin && h->n > 0 && dense_mfma_supported(h->d)) {
     DenseMfmaPlan mp;
     dense_mfma_plan((long)h->n, h->d, batched_chunk(h, nq_max), k_max, &mp);
+    if ((rc = h->smat.ensure(mp.s_bytes))) return rc;
+    if ((rc = h->part.ensure(mp.part_bytes))) return rc;
+  }
+  if (h->n > 0 && h->n <= kRowWavesMax) {  // the 1-4 query call on a short corpus also goes through S
+    DenseMfmaPlan mp;
+    dense_mfma_plan((long)h->n, h->d, nq_max < kBatchedMin ? nq_max : kBatchedMin - 1, k_max, &mp);
     if ((rc = h->smat.ensure(mp.s_bytes))) return rc;
     if ((rc = h->part.ensure(mp.part_bytes))) return rc;
   }

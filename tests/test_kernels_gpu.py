@@ -475,6 +475,30 @@ def test_bm25_fuzz_vs_oracle(nat):
         gi.close()
 
 
+def test_bm25_long_queries_token_groups(nat):
+    """Queries longer than the 64-entry token table (several table fills per query), with unknown
+    tokens, repeats and tokens whose lists are empty inside a slab: scores stay bit-exact."""
+    from oracle import bm25 as OB
+    rng = np.random.default_rng(99)
+    for n_docs in (300, 5000):
+        docs, words = toy_corpus(rng, n_docs, 400, 30)
+        ob, csr, gi = bm25_pair(nat, docs)
+        queries = []
+        for qlen in (64, 65, 129, 200):
+            q = [words[j] if rng.random() < 0.6 else f"unk{j}" for j in rng.integers(0, 400, size=qlen)]
+            q[3:6] = [q[2]] * 3  # repeats count once per occurrence
+            queries.append(q)
+        queries.append(["?"] * 70)  # nothing known at all
+        tid = [[csr["vocab"].get(t, -1) for t in q] for q in queries]
+        full = gi.get_scores(tid)
+        s, i = gi.search(tid, 10)
+        for qn, q in enumerate(queries):
+            assert np.array_equal(full[qn], ob.get_scores(q))
+            exp = OB.search(ob, q, 10)
+            assert i[qn].tolist() == [e[0] for e in exp] and s[qn].tolist() == [e[1] for e in exp]
+        gi.close()
+
+
 def test_dense_score_rows_and_edges(nat):
     rng = np.random.default_rng(8)
     X = unit_rows(rng, 500, 768)
