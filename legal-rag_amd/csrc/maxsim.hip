@@ -273,7 +273,7 @@ namespace {
 
 int ms_run(amdr_maxsim* h, const float* Q_dev, int nq, int q_len, int k, float* full_dev, float* scores_dev,
            int64_t* ids_dev, hipStream_t st) {
-  if (nq >= kMsQ) {  // batches: document tiles shared by 8 queries through LDS
+  if (nq >= kMsQ && ceil_div(h->n_docs, kMsDocs) <= 65535) {  // batches: document tiles shared by 8 queries through LDS
     dim3 grid(ceil_div(nq, kMsQ), ceil_div(h->n_docs, kMsDocs));
     hipLaunchKernelGGL(maxsim_scores_blocked_kernel, grid, dim3(kMsQ * 64), 0, st, h->D, h->doc_ptr, (long)h->n_docs,
                        (long)h->n_tokens, Q_dev, nq, q_len, full_dev);
