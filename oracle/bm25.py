@@ -18,7 +18,12 @@ restated below operation by operation so that float64 results are bit-equal:
   score[d] += idf(t) * ( tf*(k1+1) / ( tf + k1*(1 - b + b*len[d]/avgdl) ) )
              once per query token, in query order, duplicates counted,
              unknown tokens contribute idf 0.
-Parity unpinned against the wheel itself (see oracle/__init__.py); a
+Pinned only weakly: the wheel is absent and the reference's tests hold no BM25
+numbers, so the one external known answer is the example printed in rank_bm25's own
+README ("windy London" over three sentences -> [0, 0.93729472, 0], 8 digits; it
+exercises the idf formula, the epsilon floor and the length normalisation) —
+tests/test_oracle_selfcheck.py::test_bm25_matches_rank_bm25_readme_example.  Beyond
+that digit count parity with the wheel is unpinned (see oracle/__init__.py); a
 hand-checkable toy vector lives in tests/golden/bm25_toy.json.
 """
 from __future__ import annotations

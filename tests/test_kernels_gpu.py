@@ -475,6 +475,18 @@ def test_bm25_fuzz_vs_oracle(nat):
         gi.close()
 
 
+def test_bm25_rank_bm25_readme_example(nat):
+    """The product on the one published rank_bm25 vector (see tests/test_oracle_selfcheck.py)."""
+    from test_oracle_selfcheck import RANK_BM25_README_CORPUS, RANK_BM25_README_QUERY, RANK_BM25_README_SCORES
+    ob, csr, gi = bm25_pair(nat, [d.split(" ") for d in RANK_BM25_README_CORPUS])
+    tid = [[csr["vocab"].get(t, -1) for t in RANK_BM25_README_QUERY.split(" ")]]
+    full = gi.get_scores(tid)[0]
+    assert [round(float(x), 8) for x in full] == RANK_BM25_README_SCORES
+    s, i = gi.search(tid, 3)
+    assert i[0].tolist() == [1, 0, 2] and round(float(s[0, 0]), 8) == 0.93729472 and s[0, 1] == 0.0
+    gi.close()
+
+
 def test_bm25_long_queries_token_groups(nat):
     """Queries longer than the 64-entry token table (several table fills per query), with unknown
     tokens, repeats and tokens whose lists are empty inside a slab: scores stay bit-exact."""

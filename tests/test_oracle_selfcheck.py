@@ -48,6 +48,26 @@ def test_bm25_toy_golden_and_hand_check():
     assert [i for i, _ in OB.search(bm, ["zzz"], 4)] == [0, 1, 2, 3]
 
 
+# Published known answer of the upstream package: the README of rank_bm25 (0.2.x) indexes these
+# three sentences split on blanks, queries "windy London" and prints
+#     array([0.        , 0.93729472, 0.        ])
+# — the only numeric BM25Okapi vector available offline (the wheel is absent; the reference's own
+# tests hold none).  It exercises idf = ln(N-df+0.5) - ln(df+0.5), the
+# epsilon floor (the idf of "is", df = 2 of 3, is negative and becomes 0.25 * mean idf) and
+# the k1 / b length normalisation.
+RANK_BM25_README_CORPUS = ["Hello there good man!", "It is quite windy in London", "How is the weather today?"]
+RANK_BM25_README_QUERY = "windy London"
+RANK_BM25_README_SCORES = [0.0, 0.93729472, 0.0]
+
+
+def test_bm25_matches_rank_bm25_readme_example():
+    from oracle import bm25 as OB
+    ob = OB.BM25Okapi([d.split(" ") for d in RANK_BM25_README_CORPUS])
+    got = ob.get_scores(RANK_BM25_README_QUERY.split(" "))
+    assert [round(float(x), 8) for x in got] == RANK_BM25_README_SCORES
+    assert ob.idf["is"] > 0 and abs(ob.idf["is"] - 0.25 * ob.average_idf) < 1e-15  # epsilon floor applied
+
+
 def test_maxsim_golden():
     g = np.load(GOLDEN / "maxsim_golden.npz")
     rng = np.random.default_rng(42)
