@@ -309,6 +309,34 @@ def test_maxsim_blocked_equals_per_query_bitwise(nat):
     assert np.array_equal(batch, single)
 
 
+def test_maxsim_fuzz_vs_oracle(nat):
+    """Seeded sweep of both MaxSim forms (per-pair for < 8 queries, blocked otherwise): ragged
+    document lengths around the 32-token tile, document counts around the 8-document group,
+    short queries, batches that do not fill the last block."""
+    from oracle import maxsim as OM
+    rng = np.random.default_rng(20261005)
+    for it in range(14):
+        n_docs = int(rng.choice([1, 7, 8, 9, 16, 17, 63, 130]))
+        nq = int(rng.choice([1, 3, 7, 8, 9, 15, 16, 31]))
+        q_len = int(rng.choice([1, 5, 31, 32]))
+        lens = rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 100, 220], size=n_docs)
+        doc_ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        D = unit_rows(rng, int(doc_ptr[-1]), 128)
+        Q = unit_rows(rng, nq * q_len, 128).reshape(nq, q_len, 128)
+        idx = nat.MaxSimIndex(D, doc_ptr)
+        full = idx.scores(Q)
+        ref = OM.maxsim_scores(Q, D, doc_ptr)
+        assert full.shape == ref.shape and np.max(np.abs(full - ref)) <= TOL, (n_docs, nq, q_len)
+        k = int(rng.choice([1, 5, 40]))
+        s, i = idx.search(Q, k)
+        kk = min(k, n_docs)
+        for b in range(nq):
+            got = i[b, :kk]
+            assert len(set(got.tolist())) == kk and np.all(i[b, kk:] == -1)
+            assert np.max(np.abs(s[b, :kk] - ref[b, got])) <= TOL
+            assert np.all(ref[b, got] >= np.sort(ref[b])[::-1][kk - 1] - 2 * TOL)
+
+
 def test_maxsim_rejects_empty_doc(nat):
     with pytest.raises(nat.NativeError):
         nat.MaxSimIndex(np.zeros((4, 128), np.float32), np.array([0, 2, 2, 4]))
