@@ -24,6 +24,7 @@
 namespace amdr {
 
 constexpr int kBmWaves = 4;
+constexpr int kBmOneWaveDocs = 2048;  // slabs up to this size are scored and ranked by ONE wave (<= 32 scores per lane)
 
 __device__ __forceinline__ long uniform_i64(long v) {  // value known to be the same in every lane -> scalar pair
   const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long)v & 0xffffffffu));
@@ -92,9 +93,10 @@ __device__ __forceinline__ int bm25_argmax_rounds(const double* sc, int m, int k
 }
 
 // grid: (x = doc slabs, y = queries).  LDS: double sc[slab] + C64 lists[WAVES][cap] + int cnts[4] + token table [64]
-// WAVES = 1 for small slabs (one wave per query: no block barriers, no list combine),
-// 4 for full 4096-doc slabs.  With a single slab the final (scores, ids) are written
-// directly and the merge launch is skipped.
+// The host launches WAVES = 1 only (one wave per (query, slab): no block barriers, no list
+// combine) — the 4-wave form the template still allows lost at every corpus size measured
+// (bm_plan).  With a single slab the final (scores, ids) are written directly and the merge
+// launch is skipped.
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void bm25_score_topk_kernel(
     const long long* __restrict__ term_ptr, const int* __restrict__ post_doc, const double* __restrict__ post_w,
@@ -229,9 +231,9 @@ __global__ __launch_bounds__(WAVES * 64) void bm25_score_topk_kernel(
 
   WaveTopK<C64> tk;
   tk.init(lists + (size_t)wave * cap, cap, k);
-  // Short slab and shallow k (the serving shape: <= 1024 docs, k <= 16): bm25_argmax_rounds.
+  // Short slab and shallow k (the serving shape: <= 2048 docs, k <= 16): bm25_argmax_rounds.
   bool done = false;
-  if (WAVES == 1 && k <= 16 && m <= 1024) {
+  if (WAVES == 1 && k <= 16 && m <= 2048) {
     const int nv = (m + 63) >> 6;
     int got;
     if (nv <= 4)
@@ -242,8 +244,14 @@ __global__ __launch_bounds__(WAVES * 64) void bm25_score_topk_kernel(
       got = bm25_argmax_rounds<10>(sc, m, k, lo, lane, tk.buf);
     else if (nv <= 12)
       got = bm25_argmax_rounds<12>(sc, m, k, lo, lane, tk.buf);
-    else
+    else if (nv <= 16)
       got = bm25_argmax_rounds<16>(sc, m, k, lo, lane, tk.buf);
+    else if (nv <= 20)
+      got = bm25_argmax_rounds<20>(sc, m, k, lo, lane, tk.buf);
+    else if (nv <= 24)
+      got = bm25_argmax_rounds<24>(sc, m, k, lo, lane, tk.buf);
+    else
+      got = bm25_argmax_rounds<32>(sc, m, k, lo, lane, tk.buf);
     wave_lds_fence();
     tk.cnt = got;
     done = true;
@@ -328,19 +336,26 @@ namespace {
 constexpr int kSlabMax = 4096;  // docs per block: 32 KiB of fp64 scores in LDS
 
 struct BmPlan {
-  int slab, nslabs, cap, waves;
+  int slab, nslabs, cap, cap_merge, waves;
   size_t lds, part_bytes;
 };
 
 void bm_plan(int64_t n_docs, int nq, int k, BmPlan* p) {
-  p->cap = topk_cap(k);
-  p->slab = n_docs < kSlabMax ? (int)(n_docs > 0 ? n_docs : 1) : kSlabMax;
-  p->nslabs = n_docs > 0 ? (int)((n_docs + p->slab - 1) / p->slab) : 1;
-  p->waves = p->slab <= 1024 ? 1 : kBmWaves;
-  // short slab + shallow k: the kernel ranks in registers and parks only the k winners in LDS,
-  // so the candidate list shrinks from cap to 16 entries (8.3 -> 6.5 KiB per block at UCC-en
-  // size: 24 instead of 19 resident waves per CU)
-  if (p->waves == 1 && k <= 16) p->cap = 16;
+  // One wave per (query, slab) in every shape (measured on 1 260 ... 9 000 documents, 8 192
+  // queries: the 4-wave block with its per-token block barriers and list combine lost to one
+  // wave at every size — e.g. 1 260 docs, k = 10: 237 -> 74 us).  k <= 16: slabs of <= 2 048
+  // documents ranked by the register arg-max (<= 32 scores per lane), its k winners parked in
+  // a 16-entry list; deeper k: slabs of <= 4 096 ranked by the staged selector.  Slabs are
+  // balanced (3 000 documents = 2 x 1 536, not 2 048 + 952) and merged by bm25_merge_kernel.
+  const int slab_max = k <= 16 ? kBmOneWaveDocs : kSlabMax;
+  const int64_t n = n_docs > 0 ? n_docs : 1;
+  p->nslabs = (int)((n + slab_max - 1) / slab_max);
+  p->slab = (int)(((n + p->nslabs - 1) / p->nslabs + 63) / 64 * 64);
+  if (p->slab > slab_max) p->slab = slab_max;
+  p->nslabs = (int)((n + p->slab - 1) / p->slab);
+  p->waves = 1;
+  p->cap_merge = topk_cap(k);
+  p->cap = k <= 16 ? 16 : p->cap_merge;
   p->lds = (size_t)p->slab * sizeof(double) + (size_t)p->waves * p->cap * sizeof(C64) + 4 * sizeof(int) +
            64 * (2 * sizeof(long) + sizeof(double)) + 8;
   p->part_bytes = (size_t)p->nslabs * nq * k * sizeof(C64);
@@ -360,18 +375,16 @@ int bm_run(amdr_bm25* h, const int* q_terms_dev, const long long* q_ptr_dev, int
   double* fs = direct ? scores_dev : nullptr;
   long long* fi = direct ? (long long*)ids_dev : nullptr;
   if (direct) part = nullptr;
-  if (p.waves == 1)
-    hipLaunchKernelGGL(bm25_score_topk_kernel<1>, dim3(p.nslabs, nq), dim3(64), p.lds, st, h->term_ptr, h->post_doc,
-                       h->post_w, h->idf, (long)h->n_terms, (long)h->n_docs, q_terms_dev, q_ptr_dev, nq, k, p.cap,
-                       p.slab, full_dev, part, fs, fi);
-  else
-    hipLaunchKernelGGL(bm25_score_topk_kernel<kBmWaves>, dim3(p.nslabs, nq), dim3(256), p.lds, st, h->term_ptr,
-                       h->post_doc, h->post_w, h->idf, (long)h->n_terms, (long)h->n_docs, q_terms_dev, q_ptr_dev, nq,
-                       k, p.cap, p.slab, full_dev, part, fs, fi);
+  if (p.lds > 48 * 1024) {  // never with the slab limits of bm_plan (4 096 x 8 B + lists < 48 KiB); guard for edits
+    return fail(AMDR_EINVAL, "bm25: slab needs %zu B of LDS", p.lds);
+  }
+  hipLaunchKernelGGL(bm25_score_topk_kernel<1>, dim3(p.nslabs, nq), dim3(64), p.lds, st, h->term_ptr, h->post_doc,
+                     h->post_w, h->idf, (long)h->n_terms, (long)h->n_docs, q_terms_dev, q_ptr_dev, nq, k, p.cap,
+                     p.slab, full_dev, part, fs, fi);
   AMDR_HIP(hipGetLastError());
   if (scores_dev && !direct) {
-    size_t lds = (size_t)kBmWaves * p.cap * sizeof(C64) + kBmWaves * sizeof(int);
-    hipLaunchKernelGGL(bm25_merge_kernel, dim3(nq), dim3(256), lds, st, part, p.nslabs, nq, k, p.cap, scores_dev,
+    size_t lds = (size_t)kBmWaves * p.cap_merge * sizeof(C64) + kBmWaves * sizeof(int);
+    hipLaunchKernelGGL(bm25_merge_kernel, dim3(nq), dim3(256), lds, st, part, p.nslabs, nq, k, p.cap_merge, scores_dev,
                        (long long*)ids_dev);
     AMDR_HIP(hipGetLastError());
   }
