@@ -264,6 +264,8 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
   }
 }
 
+constexpr int kSelectRowsMax = 2048;  // rows one wave ranks in registers (<= 32 keys per lane)
+
 template <int V>
 __device__ __forceinline__ int select_row(const float* __restrict__ row, long lo, long hi, int k, int lane, C32* buf) {
   C32 keys[V];
@@ -295,16 +297,21 @@ __global__ __launch_bounds__(WAVES * 64) void scores_slab_topk_kernel(const floa
   WaveTopK<C32> tk;
   tk.init(lists + (size_t)wave * cap, cap, k);
   bool done = false;
-  if (WAVES == 1 && k <= 64 && hi - lo <= 1024) {
+  if (WAVES == 1 && k <= 64 && hi - lo <= kSelectRowsMax) {
     // short row: register selector (topk.hpp); scratch = the upper half of the staging buffer.
-    // V = keys per lane, sized to the row (a UCC-en row of 591 scores needs 10, not 16).
+    // V = keys per lane, sized to the row (a UCC-en row of 591 scores needs 10, a
+    // Civil-Code-zh row of 1 260 needs 20).
     int got;
     if (hi - lo <= 256)
       got = select_row<4>(row, lo, hi, k, lane, tk.buf);
     else if (hi - lo <= 640)
       got = select_row<10>(row, lo, hi, k, lane, tk.buf);
-    else
+    else if (hi - lo <= 1024)
       got = select_row<16>(row, lo, hi, k, lane, tk.buf);
+    else if (hi - lo <= 1280)
+      got = select_row<20>(row, lo, hi, k, lane, tk.buf);
+    else
+      got = select_row<32>(row, lo, hi, k, lane, tk.buf);
     if (got >= 0) {
       tk.cnt = got;
       done = true;
@@ -458,7 +465,7 @@ int dense_mfma_launch_scores(const DenseMfmaPlan& p, const float* X, long n, int
 
 int dense_mfma_launch_topk(const DenseMfmaPlan& p, const float* S, long n, int nq, int k, void* part,
                            float* fin_scores, int64_t* fin_ids, hipStream_t st) {
-  const int waves = p.rows_per_slab <= 1024 ? 1 : kBW;
+  const int waves = p.rows_per_slab <= kSelectRowsMax ? 1 : kBW;
   size_t lds = (size_t)waves * p.cap * sizeof(C32) + waves * sizeof(int);
   if (waves == 1)
     hipLaunchKernelGGL(scores_slab_topk_kernel<1>, dim3(p.slabs, nq), dim3(64), lds, st, S, p.ld, n, nq, k, p.cap,
