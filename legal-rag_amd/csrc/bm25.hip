@@ -24,6 +24,12 @@
 namespace amdr {
 
 constexpr int kBmWaves = 4;
+constexpr int kBmArgmaxK = 96;  // deepest k ever ranked by arg-max rounds (one round per result)
+// Arg-max rounds cost ~ k x (scores per lane); the staged selector is nearly flat in k.  Measured
+// crossover (scripts/sweep_bm25.py, 591 and 1 260 documents, k = 10 ... 80): k x ceil(slab / 64) ~ 480.
+__host__ __device__ inline bool bm_use_argmax(int k, int slab) {
+  return slab <= 2048 && (k <= 16 || (k <= kBmArgmaxK && k * ((slab + 63) >> 6) <= 480));
+}
 constexpr int kBmOneWaveDocs = 2048;  // slabs up to this size are scored and ranked by ONE wave (<= 32 scores per lane)
 
 __device__ __forceinline__ long uniform_i64(long v) {  // value known to be the same in every lane -> scalar pair
@@ -231,9 +237,9 @@ __global__ __launch_bounds__(WAVES * 64) void bm25_score_topk_kernel(
 
   WaveTopK<C64> tk;
   tk.init(lists + (size_t)wave * cap, cap, k);
-  // Short slab and shallow k (the serving shape: <= 2048 docs, k <= 16): bm25_argmax_rounds.
+  // Short slab and shallow k (bm_use_argmax; the serving shape is 591 docs, k = 10): bm25_argmax_rounds.
   bool done = false;
-  if (WAVES == 1 && k <= 16 && m <= 2048) {
+  if (WAVES == 1 && bm_use_argmax(k, slab)) {
     const int nv = (m + 63) >> 6;
     int got;
     if (nv <= 4)
@@ -343,19 +349,24 @@ struct BmPlan {
 void bm_plan(int64_t n_docs, int nq, int k, BmPlan* p) {
   // One wave per (query, slab) in every shape (measured on 1 260 ... 9 000 documents, 8 192
   // queries: the 4-wave block with its per-token block barriers and list combine lost to one
-  // wave at every size — e.g. 1 260 docs, k = 10: 237 -> 74 us).  k <= 16: slabs of <= 2 048
-  // documents ranked by the register arg-max (<= 32 scores per lane), its k winners parked in
-  // a 16-entry list; deeper k: slabs of <= 4 096 ranked by the staged selector.  Slabs are
-  // balanced (3 000 documents = 2 x 1 536, not 2 048 + 952) and merged by bm25_merge_kernel.
-  const int slab_max = k <= 16 ? kBmOneWaveDocs : kSlabMax;
+  // wave at every size — e.g. 1 260 docs, k = 10: 237 -> 74 us).  Shallow k (bm_use_argmax):
+  // slabs of <= 2 048 documents ranked by the register arg-max (<= 32 scores per lane), its k
+  // winners parked in a short list; otherwise slabs of <= 4 096 ranked by the staged selector.
+  // Slabs are balanced (3 000 documents = 2 x 1 536, not 2 048 + 952) and merged by
+  // bm25_merge_kernel.
   const int64_t n = n_docs > 0 ? n_docs : 1;
-  p->nslabs = (int)((n + slab_max - 1) / slab_max);
-  p->slab = (int)(((n + p->nslabs - 1) / p->nslabs + 63) / 64 * 64);
-  if (p->slab > slab_max) p->slab = slab_max;
-  p->nslabs = (int)((n + p->slab - 1) / p->slab);
+  auto balanced = [&](int slab_max) {
+    p->nslabs = (int)((n + slab_max - 1) / slab_max);
+    p->slab = (int)(((n + p->nslabs - 1) / p->nslabs + 63) / 64 * 64);
+    if (p->slab > slab_max) p->slab = slab_max;
+    p->nslabs = (int)((n + p->slab - 1) / p->slab);
+  };
+  balanced(kBmOneWaveDocs);
+  const bool argmax = bm_use_argmax(k, p->slab);
+  if (!argmax) balanced(kSlabMax);
   p->waves = 1;
   p->cap_merge = topk_cap(k);
-  p->cap = k <= 16 ? 16 : p->cap_merge;
+  p->cap = argmax ? (k <= 16 ? 16 : kBmArgmaxK) : p->cap_merge;
   p->lds = (size_t)p->slab * sizeof(double) + (size_t)p->waves * p->cap * sizeof(C64) + 4 * sizeof(int) +
            64 * (2 * sizeof(long) + sizeof(double)) + 8;
   p->part_bytes = (size_t)p->nslabs * nq * k * sizeof(C64);

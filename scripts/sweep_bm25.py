@@ -23,7 +23,7 @@ tid=[[int(t) for t in rng.choice(vocab,size=8,p=p)] for _ in range(nq)]
 qt,qp=_native.BM25Index.pack_queries(tid)
 dev=torch.device('cuda',0)
 qtd=torch.from_numpy(qt).to(dev); qpd=torch.from_numpy(qp).to(dev)
-for k in (10,80):
+for k in (10,20,32,48,64,80):
     s=torch.empty((nq,k),dtype=torch.float64,device=dev); i=torch.empty((nq,k),dtype=torch.int64,device=dev)
     gi.reserve(nq,k,len(qt))
     st=int(torch.cuda.current_stream().cuda_stream)
