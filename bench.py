@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="ucc_hybrid", choices=["ucc_hybrid", "ucc_colbert", "synth10m"])
     ap.add_argument("--shard", default="auto", choices=["auto", "queries", "corpus"])
-    ap.add_argument("--repeat", type=int, default=8, help="ucc_hybrid: the query set is tiled this many times per step")
+    ap.add_argument("--repeat", type=int, default=32, help="ucc_hybrid: the query set is tiled this many times per step")
     ap.add_argument("--synth-rows", type=int, default=10_000_000)
     ap.add_argument("--synth-batch", type=int, default=8)
     ap.add_argument("--no-hbm-scan", action="store_true")
@@ -397,7 +397,7 @@ def main():
         roofline = {"bound": "mfma", "kernel": "dense_mfma_scores_kernel (v_mfma_f32_32x32x2_f32, exact fp32)",
                     "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / F32_MFMA_PEAK_TFLOPS,
-                    "traffic": pmc_traffic("ucc_hybrid/dense_mfma_scores_kernel") if (not with_colbert and rep == 8
+                    "traffic": pmc_traffic("ucc_hybrid/dense_mfma_scores_kernel") if (not with_colbert and rep == 32
                                                                                      and shard == "queries") else None,
                     "launch_ms": per_launch_ms,
                     "algorithmic_flops": flops_per_launch,
