@@ -394,7 +394,7 @@ def main():
         flops_per_launch = 2.0 * rows_local * d * nq
         per_launch_ms = scan_ms / max(launches, 1)
         achieved = flops_per_launch / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
-        roofline = {"bound": "mfma", "kernel": "dense_mfma_scores_kernel (v_mfma_f32_32x32x2_f32, exact fp32)",
+        roofline = {"bound": "mfma", "kernel": "dense_mfma_scores_kernel (v_mfma_f32_16x16x4_f32, exact fp32)",
                     "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / F32_MFMA_PEAK_TFLOPS,
                     "traffic": pmc_traffic("ucc_hybrid/dense_mfma_scores_kernel") if (not with_colbert and rep == 32

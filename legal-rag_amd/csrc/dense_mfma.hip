@@ -4,21 +4,22 @@
 // `index.search`, legalrag/retrieval/dense_retriever.py:42) for query batches.
 // With B queries per pass the scan is a [n x d] . [d x B] product; beyond ~8
 // queries the per-(row, query) cross-lane reductions of the GEMV form saturate
-// the vector ALU before HBM, so the batch is tiled 32 queries wide on the
-// fp32-input matrix instruction v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 fmaf
-// chain (exact fp32 — no TF32/bf16 shortcut exists or is wanted), the same peak
-// rate as the vector ALU, but the 32x32 accumulate needs no cross-lane traffic.
-//   A (32 queries x 2): lane (i = l&31, h = l>>5) <- Q[q0+i][k]   (LDS, staged once per block)
-//   B (2 x 32 rows)   : lane (j = l&31, h)        <- X[r0+j][k]   (HBM -> registers -> LDS -> registers)
-// X is fetched with fully coalesced 16-B/lane loads (8 rows x 128 B per wave
-// instruction, each byte of X read from HBM exactly once), parked in a wave-private,
-// XOR-swizzled 4-KiB LDS stage and read back row-per-lane as the MFMA wants it; four
-// 32-float chunks per wave (128 KiB per CU with 8 waves) are always in flight in registers.
-// The k order inside a chunk is permuted (lane half h takes slots 4h..4h+3); A and B use
-// the same permutation, which a dot product cannot see.  C[query][row] comes
-// back with the row on the lane, so each accumulator register is stored as two
-// 128-byte segments of the score matrix S[query][row].  Top-k is a second,
-// slab-parallel pass over S (+8 % traffic at d = 768: 128 B written and read per
+// the vector ALU before HBM, so the batch is tiled 32 queries x 32 rows per wave on the
+// fp32-input matrix instruction v_mfma_f32_16x16x4_f32 (four 16x16 accumulator blocks): exact
+// fp32 products and accumulation (no TF32/bf16 shortcut exists or is wanted), the same peak
+// rate as the vector ALU, but the accumulate needs no cross-lane traffic.  (The tile was first
+// built on v_mfma_f32_32x32x2_f32 — same flops per cycle on paper; the 16x16 form measured
+// 7.5 % faster on the UCC-en launch in a same-box A/B: the chip holds a higher clock on it.)
+//   A (16 x 4): lane (i16 = l&15, kq = l>>4) <- LDS tile row 16b + i16   (staged once per block)
+//   B (4 x 16): lane (i16, kq)              <- streamed row 16b + i16    (HBM -> registers -> LDS -> registers)
+// The streamed operand is fetched with fully coalesced 16-B/lane loads (8 rows x 128 B per wave
+// instruction, each byte read from HBM exactly once), parked in a wave-private, XOR-swizzled
+// 4-KiB LDS stage and read back as fragments; four 32-float chunks per wave (128 KiB per CU
+// with 8 waves) are always in flight in registers.  The k order inside a chunk is permuted
+// (lane group kq takes 16-B slots kq and 4 + kq); both operands use the same permutation,
+// which a dot product cannot see.  The finished 32x32 tile is turned through the wave's LDS
+// stage and stored as whole 128-byte rows of the score matrix S[query][row].  Top-k is a
+// second, slab-parallel pass over S (+8 % traffic at d = 768: 128 B written and read per
 // 3072-B row per 32 queries).
 #include "common.hpp"
 #include "topk.hpp"
@@ -28,7 +29,7 @@
 
 namespace amdr {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));  // native vector: stays in registers (HIP's float4 struct did not)
 
 constexpr int kBW = 4;          // waves per block
@@ -43,7 +44,6 @@ constexpr int kStageBytes = 32 * kKC * 4;  // 4 KiB: one 32-row x 32-float chunk
 constexpr int kStageBufs = AMDR_STAGE_BUFS;
 constexpr int kPieces = kStageBytes / 1024;  // 1-KiB wave loads per chunk (4): 8 rows x 128 B each
 constexpr int kDepth = 4;                      // chunks in flight from HBM per wave (16 KiB)
-constexpr int kFr = kKC / 8;                  // float4 fragments per lane and chunk (4): its half of the 8 slots
 
 // LDS image of a staged chunk: row r (0..31) at byte r*128 — two rows share one 256-B bank
 // row — with its logical 16-B slot s (0..7) at physical slot s ^ ((r >> 1) & 7).  A
@@ -57,45 +57,40 @@ __device__ __forceinline__ int stage_off(int row, int slot) { return row * 128 +
 #define AMDR_STAGE_CHUNK(ST, G)                                                                   \
   _Pragma("unroll") for (int p_ = 0; p_ < kPieces; ++p_)                                          \
       *reinterpret_cast<v4f*>((ST) + stage_off(8 * p_ + lrow, lslot)) = G[p_];
+// Fragments of one 32-float chunk.  v_mfma_f32_16x16x4_f32 takes A[row l&15][k = l>>4] and
+// B[k = l>>4][col l&15], one float per lane, so a lane (i16 = l & 15, kq = l >> 4) owns, for each
+// of the two 16-row blocks b of the tile, the 16-B slots 4u + kq (u = 0, 1) of row 16b + i16: the
+// chunk's eight k-steps take component (u, x..w) of those slots from the four kq groups — a
+// permutation of k that both operands share.  Slot choice 4u + kq keeps both images
+// conflict-free: a ds_read_b128 lane group {0-3, 12-15, 20-27} (and its three siblings) holds 16
+// distinct rows, eight at slot 4u + kq and eight at 4u + (kq ^ 1), and the row swizzles map
+// exactly those two sets onto disjoint bank quads.
 #define AMDR_READ_FRAGS(ST, C, FX, FQ)                                                            \
-  _Pragma("unroll") for (int m_ = 0; m_ < kFr; ++m_) {                                            \
-    FX[m_] = *reinterpret_cast<const v4f*>((ST) + stage_off(i, h * kFr + m_));                    \
-    FQ[m_] = qsv[i * (d / 4) + ((((C) * 2 * kFr + h * kFr + m_)) ^ (i & 15))];                    \
+  _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_) {                                              \
+    _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_) {                                            \
+      FX[b_][u_] = *reinterpret_cast<const v4f*>((ST) + b_ * 2048 + xoff[u_]);                    \
+      FQ[b_][u_] = qrow[b_ * 16 * (d / 4) + ((C) >> 1) * 16 + qlow[(C) & 1][u_]];                 \
+    }                                                                                             \
   }
 #if defined(AMDR_ABLATE) && AMDR_ABLATE == 1  // timing-only build: matrix pipe removed, operands kept live
-#define AMDR_MFMA_CHUNK(FX, FQ)                                                                   \
-  _Pragma("unroll") for (int m_ = 0; m_ < kFr; ++m_) {                                            \
-    acc[m_] += FQ[m_].x * FX[m_].x + FQ[m_].y * FX[m_].y + FQ[m_].z * FX[m_].z + FQ[m_].w * FX[m_].w; \
-  }
+#define AMDR_MFMA_STEP(A_, B_, BI, BJ) acc[BI][BJ].x += (A_) * (B_);
 #else
-#define AMDR_MFMA_CHUNK(FX, FQ)                                                                   \
-  _Pragma("unroll") for (int m_ = 0; m_ < kFr; ++m_) {                                            \
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FQ[m_].x, FX[m_].x, acc, 0, 0, 0);                 \
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FQ[m_].y, FX[m_].y, acc, 0, 0, 0);                 \
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FQ[m_].z, FX[m_].z, acc, 0, 0, 0);                 \
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FQ[m_].w, FX[m_].w, acc, 0, 0, 0);                 \
-  }
+#define AMDR_MFMA_STEP(A_, B_, BI, BJ) acc[BI][BJ] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_, B_, acc[BI][BJ], 0, 0, 0);
 #endif
-// Issue pattern of one half step (sched_group_barrier masks: 0x008 MFMA, 0x020 VMEM read,
-// 0x100 DS read, 0x200 DS write): 8 x {MFMA, ds_write, global_load}, 16 x {MFMA, ds_read}, 8 x MFMA.
-// Measured A/B in one process on one device (rule 24): leaving this region to hipcc's own
-// scheduler is 2-7 % FASTER than the pinned pattern (B=8 scan 5.27 vs 5.67 ms, B=32 6.16 vs
-// 6.25-6.8 ms, UCC step kernel 122 vs 127 us), so the pattern is opt-in only.
-#if !defined(AMDR_PIN_SCHEDULE)
+// 8 k-steps x 4 accumulator blocks = 32 MFMAs of 32 cycles per chunk; an accumulator is touched
+// every fourth instruction, well past the 40-cycle dependent latency.
+#define AMDR_MFMA_KSTEP(FX, FQ, U, COMP)                                                          \
+  AMDR_MFMA_STEP(FQ[0][U].COMP, FX[0][U].COMP, 0, 0)                                              \
+  AMDR_MFMA_STEP(FQ[0][U].COMP, FX[1][U].COMP, 0, 1)                                              \
+  AMDR_MFMA_STEP(FQ[1][U].COMP, FX[0][U].COMP, 1, 0)                                              \
+  AMDR_MFMA_STEP(FQ[1][U].COMP, FX[1][U].COMP, 1, 1)
+#define AMDR_MFMA_CHUNK(FX, FQ)                                                                   \
+  AMDR_MFMA_KSTEP(FX, FQ, 0, x) AMDR_MFMA_KSTEP(FX, FQ, 0, y) AMDR_MFMA_KSTEP(FX, FQ, 0, z)       \
+  AMDR_MFMA_KSTEP(FX, FQ, 0, w) AMDR_MFMA_KSTEP(FX, FQ, 1, x) AMDR_MFMA_KSTEP(FX, FQ, 1, y)       \
+  AMDR_MFMA_KSTEP(FX, FQ, 1, z) AMDR_MFMA_KSTEP(FX, FQ, 1, w)
+// (Pinning an MFMA / ds_write / global_load / ds_read interleave with sched_group_barrier was
+// measured 2-7 % SLOWER than hipcc's own schedule of this region and is not kept.)
 #define AMDR_INTERLEAVE()
-#else
-#define AMDR_INTERLEAVE()                                                                         \
-  _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                              \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                            \
-    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                            \
-    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                            \
-  }                                                                                               \
-  _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) {                                             \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                            \
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                            \
-  }                                                                                               \
-  __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-#endif
 
 #if defined(AMDR_ABLATE) && AMDR_ABLATE == 2  // timing-only build: no X traffic (registers filled from an address hash)
 #define AMDR_LDX(PTR) ([&] { v4f z_; z_.x = z_.y = z_.z = z_.w = (float)(((size_t)(PTR)) & 1023) * 1e-3f; return z_; }())
@@ -125,7 +120,20 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
   const v4f* qsv = reinterpret_cast<const v4f*>(smem);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned char* stage = smem + (size_t)d * 128 + (size_t)wave * kStageBufs * kStageBytes;
-  const int i = lane & 31, h = lane >> 5;
+  const int i = lane & 31, h = lane >> 5;  // store roles (epilogue)
+  const int i16 = lane & 15, kq = lane >> 4;  // MFMA fragment roles
+  // Lane-dependent parts of the fragment addresses, computed once: every other term is a
+  // compile-time constant of the unrolled chunk loop and folds into the ds_read offset field.
+  //   stage: row 16 b + i16, slot 4 u + kq -> b * 2048 + i16 * 128 + ((4u + kq) ^ (i16 >> 1)) * 16
+  //   LDS tile: row 16 b + i16, slot 8 C + 4 u + kq, XOR i16 touches the low four bits only
+  int xoff[2], qlow[2][2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    xoff[u] = stage_off(i16, 4 * u + kq);
+    qlow[0][u] = (4 * u + kq) ^ i16;
+    qlow[1][u] = (8 + 4 * u + kq) ^ i16;
+  }
+  const v4f* qrow = qsv + i16 * (d / 4);
   // Block id -> (slab bx of the streamed operand, tile by of the LDS operand).  The grid is 1-D and
   // remapped so that each XCD (blocks with equal id % 8 share one; 8 XCDs, each with its own L2)
   // owns a CONTIGUOUS range of the slab-major order: the `gy` blocks that stream the same slab
@@ -200,7 +208,7 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
     //   stage[c & 1]   this wave's LDS image of chunk c (swizzled, double-buffered)
     //   FX/FQ[c & 1]   MFMA fragments of chunk c, read from LDS one chunk AHEAD of their use so
     //                  the dependent MFMA chain never waits on an LDS round trip.
-    v4f G[kDepth][kPieces], FX[2][kFr], FQ[2][kFr];
+    v4f G[kDepth][kPieces], FX[2][2][2], FQ[2][2][2];
 #pragma unroll
     for (int j = 0; j < kDepth; ++j) {
       if (j < NCH) {
@@ -215,10 +223,14 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
     }
     wave_lds_fence();
     AMDR_READ_FRAGS(stage, 0, FX[0], FQ[0])
-    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[2][2];  // acc[bi][bj][r] = C[LDS-tile row 16 bi + 4 kq + r][streamed row 16 bj + i16]
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+      for (int bj = 0; bj < 2; ++bj) acc[bi][bj] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      // One scheduling region per chunk: the 16 dependent MFMAs of chunk c and, in their shadow,
+      // One scheduling region per chunk: the 32 MFMAs of chunk c and, in their shadow,
       // the staging of chunk c+1 (4 ds_write), the refill of its registers with chunk
       // c+1+kDepth (4 loads) and its fragment reads (8 ds_read).  The LDS unit serves a wave's
       // operations in order and the compiler keeps the may-alias write->read order on `stage`.
@@ -235,32 +247,33 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
       AMDR_INTERLEAVE()
       wave_lds_fence();
     }
-    if (!TR) {
-      const long r = r0 + i;
-      if (r < row_hi) {
+    // The 32x32 tile goes through the wave's LDS stage (T[ti][tj] at ti*32 + (tj ^ ti): conflict-
+    // free to read along either index) so that S[query][chunk row] is written as whole 128-byte
+    // rows, two per instruction, in both orientations.  ti = row of the LDS tile, tj = streamed row.
+    float* tf = reinterpret_cast<float*>(stage);
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          const int qrow = (g & 3) + 8 * (g >> 2) + 4 * h;  // C/D map: row = query within the tile
-          if (q0 + qrow < nq) S[(size_t)(q0 + qrow) * ldS + r] = acc[g];
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+      for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ti = 16 * bi + 4 * kq + r, tj = 16 * bj + i16;
+          tf[ti * 32 + (tj ^ ti)] = acc[bi][bj][r];
         }
-      }
-    } else {
-      // lane i holds streamed row r0+i (a query) against the 16 tiled rows qrow(g, h) (chunks):
-      // park the 32x32 tile in the wave's stage as T[i][qrow ^ i] (4 KiB, column index XOR row:
-      // conflict-free both ways), read it back with the chunk index on the lane, store
-      // 2 x 128 B per instruction.
-      float* tf = reinterpret_cast<float*>(stage);
+    wave_lds_fence();
 #pragma unroll
-      for (int g = 0; g < 16; ++g) tf[i * 32 + (((g & 3) + 8 * (g >> 2) + 4 * h) ^ i)] = acc[g];
-      wave_lds_fence();
-#pragma unroll
-      for (int p = 0; p < 16; ++p) {
-        const int rr = 2 * p + h;
-        const float v = tf[rr * 32 + (i ^ rr)];
-        if (r0 + rr < row_hi && q0 + i < nq) S[(size_t)(r0 + rr) * ldS + q0 + i] = v;
+    for (int p = 0; p < 16; ++p) {
+      if (!TR) {  // LDS tile = queries q0 + ti, streamed = chunk rows r0 + tj
+        const int ti = 2 * p + h, tj = i;
+        const float v = tf[ti * 32 + (tj ^ ti)];
+        if (q0 + ti < nq && r0 + tj < row_hi) S[(size_t)(q0 + ti) * ldS + r0 + tj] = v;
+      } else {  // LDS tile = chunk rows q0 + ti, streamed = queries r0 + tj
+        const int tj = 2 * p + h, ti = i;
+        const float v = tf[ti * 32 + (tj ^ ti)];
+        if (r0 + tj < row_hi && q0 + ti < nq) S[(size_t)(r0 + tj) * ldS + q0 + ti] = v;
       }
-      wave_lds_fence();  // the next tile's first chunk is staged over T
     }
+    wave_lds_fence();  // the next tile's first chunk is staged over T
   }
 }
 
