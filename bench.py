@@ -416,7 +416,7 @@ def main():
             ms_ms = e0.elapsed_time(e1) / reps
             tokens = int(W["doc_ptr"][-1])
             ms_flops = 2.0 * q_tok.shape[1] * q_tok.shape[2] * tokens * nq
-            roofline = {"bound": "mfma", "kernel": "maxsim_scores_kernel + rowscores_topk_kernel (v_mfma_f32_32x32x2_f32)",
+            roofline = {"bound": "mfma", "kernel": "maxsim_scores_blocked_kernel + rowscores_topk_kernel (v_mfma_f32_16x16x4_f32)",
                         "achieved": ms_flops / (ms_ms * 1e-3) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": ms_flops / (ms_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, "traffic": None,
                         "launch_ms": ms_ms, "algorithmic_flops": ms_flops,

@@ -2,18 +2,17 @@
 //
 // Replaces `Searcher.search(query, k)` (legalrag/retrieval/colbert_retriever.py:152):
 //   score(q, doc) = sum_{i < q_len} max_{j < len(doc)} <q_i, d_j>,  dim = 128, fp32.
-// One wave scores one (query, document) pair.  The 32 x len similarity tile is
-// a genuine small matrix product, so it runs on the matrix cores with the
-// fp32-input v_mfma_f32_32x32x2_f32 (bit-for-bit an fp32 fmaf chain, i.e. the
-// same arithmetic as a VALU dot product, at the same peak rate, but with no
-// cross-lane reduction and no LDS broadcast traffic):
-//   A (32 tokens x 2)  : lane (j = l&31, h = l>>5) holds D[tok0 + j][64h + kk]
-//   B (2 x 32 q-tokens): lane (i = l&31, h = l>>5) holds Q[i][64h + kk]
-// i.e. the k index is permuted so that every lane reads ONE contiguous 256-byte
-// half row; a dot product does not care about the order of its terms as long as
-// A and B agree.  C[token][q-token] comes back with the q-token on the lane and
-// 16 tokens in the lane's registers, so max-over-tokens is in-register and the
-// final sum over q-tokens is one DPP reduction per document.
+// A wave scores (query, document) pairs tile by tile: the 32 query tokens x 32 document tokens
+// similarity tile is a genuine small matrix product, so it runs on the matrix cores with the
+// fp32-input v_mfma_f32_16x16x4_f32 (exact fp32 products and sums, the peak rate of the vector
+// ALU, no cross-lane reduction, no LDS broadcast traffic), four 16x16 accumulator blocks:
+//   A (16 doc tokens x 4)   : lane (i16 = l&15, kq = l>>4) holds D[tok0 + 16 bi + i16][16-B slots 4t + kq]
+//   B (4 x 16 query tokens) : lane (i16, kq)              holds Q[16 bj + i16][16-B slots 4t + kq]
+// (t = 0..7: the k index is permuted, identically for both operands — a dot product does not
+// care.)  C[doc token][query token] comes back with the query token on the lane (l & 15) and
+// 4 doc tokens per accumulator block in the lane's registers, so max-over-tokens is in-register
+// plus two lane exchanges, and the final sum over query tokens is one DPP reduction per document.
+// (First built on v_mfma_f32_32x32x2_f32; the 16x16 form holds a higher clock, see dense_mfma.hip.)
 // Algorithmic bytes per (query, shard): sum_docs len*128*4; flops 2*32*128*sum len.
 #include "common.hpp"
 #include "topk.hpp"
@@ -24,11 +23,9 @@
 
 namespace amdr {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kMsWaves = 4;
 constexpr int kDim = AMDR_MAXSIM_DIM;  // 128
-constexpr int kHalf = kDim / 2;        // 64 floats per lane
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float ms_dpp_add(float v) {
@@ -45,18 +42,73 @@ __device__ __forceinline__ float ms_wave_sum(float v) {  // total in lane 63
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-__device__ __forceinline__ void load_half_row(const float* __restrict__ p, float (&r)[kHalf]) {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float ms4f __attribute__((ext_vector_type(4)));
+
+// One 32x32 tile: 8 slots x 4 components x (2 x 2 accumulator blocks) = 128 MFMAs of 32 cycles.
+// a[bi][t] / q[bj][t]: the lane's 16-B slot 4t + kq of document-token row 16 bi + i16 / query-token
+// row 16 bj + i16.  Returns, per query-token block bj, the maximum over this lane's 8 document
+// tokens (rows 16 bi + 4 kq + r), rows >= remain masked out.
+__device__ __forceinline__ void ms_tile(const ms4f (&a)[2][8], const ms4f (&q)[2][8], int kq, int remain,
+                                        float (&best)[2]) {
+  f32x4 acc[2][2];
 #pragma unroll
-  for (int m = 0; m < kHalf / 4; ++m) {
-    float4 v = *reinterpret_cast<const float4*>(p + 4 * m);
-    r[4 * m + 0] = v.x;
-    r[4 * m + 1] = v.y;
-    r[4 * m + 2] = v.z;
-    r[4 * m + 3] = v.w;
+  for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj) acc[bi][bj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define AMDR_MS_K(T, COMP)                                                                                  \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][T].COMP, q[0][T].COMP, acc[0][0], 0, 0, 0);         \
+  acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][T].COMP, q[1][T].COMP, acc[0][1], 0, 0, 0);         \
+  acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][T].COMP, q[0][T].COMP, acc[1][0], 0, 0, 0);         \
+  acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][T].COMP, q[1][T].COMP, acc[1][1], 0, 0, 0);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    AMDR_MS_K(t, x) AMDR_MS_K(t, y) AMDR_MS_K(t, z) AMDR_MS_K(t, w)
+  }
+#undef AMDR_MS_K
+#pragma unroll
+  for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool off = remain < 32 && (16 * bi + 4 * kq + r) >= remain;
+#pragma unroll
+      for (int bj = 0; bj < 2; ++bj) best[bj] = fmaxf(best[bj], off ? -FLT_MAX : acc[bi][bj][r]);
+    }
+}
+
+// Document score from the per-lane maxima: max over the four kq groups, then sum over the
+// q_len query tokens (lane group kq = 0 holds token 16 bj + i16 in best[bj]).
+__device__ __forceinline__ float ms_finish(const float (&best)[2], int i16, int kq, int q_len) {
+  float contrib = 0.f;
+#pragma unroll
+  for (int bj = 0; bj < 2; ++bj) {
+    float b = best[bj];
+    b = fmaxf(b, __uint_as_float(lane_xor<16>(__float_as_uint(b))));
+    b = fmaxf(b, __uint_as_float(lane_xor<32>(__float_as_uint(b))));
+    if (kq == 0 && 16 * bj + i16 < q_len) contrib += b;
+  }
+  return ms_wave_sum(contrib);
+}
+
+// The lane's fragment of a 32-row x 128-float operand in global memory: rows row0 + 16 b + i16
+// (clamped to row_max), 16-B slots 4t + kq.
+__device__ __forceinline__ void ms_load_frag(const float* __restrict__ base, long row0, long row_max, int i16, int kq,
+                                             bool zero, ms4f (&f)[2][8]) {
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    long row = row0 + 16 * b + i16;
+    const bool out = zero && row > row_max;
+    if (row > row_max) row = row_max;
+    const float* p = base + (size_t)row * kDim + kq * 4;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const ms4f v = *reinterpret_cast<const ms4f*>(p + 16 * t);
+      f[b][t] = out ? ms4f{0.f, 0.f, 0.f, 0.f} : v;
+    }
   }
 }
 
-// grid: (x = ceil(n_docs / 4), y = queries); one wave per document.
+// grid: (x = ceil(n_docs / 4), y = queries); one wave per document (1-7 queries: latency form).
 __global__ __launch_bounds__(256) void maxsim_scores_kernel(const float* __restrict__ D,
                                                              const long long* __restrict__ doc_ptr, long n_docs,
                                                              const float* __restrict__ Q, int q_len,
@@ -65,42 +117,20 @@ __global__ __launch_bounds__(256) void maxsim_scores_kernel(const float* __restr
   const long doc = (long)blockIdx.x * kMsWaves + wave;
   if (doc >= n_docs) return;  // whole wave exits together
   const int qi = blockIdx.y;
-  const int r = lane & 31, h = lane >> 5;
+  const int i16 = lane & 15, kq = lane >> 4;
 
-  float qreg[kHalf];
-  if (r < q_len) {
-    load_half_row(Q + ((size_t)qi * q_len + r) * kDim + h * kHalf, qreg);
-  } else {
-#pragma unroll
-    for (int m = 0; m < kHalf; ++m) qreg[m] = 0.f;
-  }
+  ms4f qf[2][8];  // query tokens past q_len are zero rows
+  ms_load_frag(Q + (size_t)qi * q_len * kDim, 0, q_len - 1, i16, kq, true, qf);
 
   const long t_lo = doc_ptr[doc], t_hi = doc_ptr[doc + 1];
   const int len = (int)(t_hi - t_lo);
-  float best = -FLT_MAX;  // running max over this lane's token rows, for q-token r
-
+  float best[2] = {-FLT_MAX, -FLT_MAX};
   for (int tok0 = 0; tok0 < len; tok0 += 32) {
-    int j = tok0 + r;
-    if (j >= len) j = len - 1;  // clamp: rows past the end are masked below
-    float areg[kHalf];
-    load_half_row(D + (size_t)(t_lo + j) * kDim + h * kHalf, areg);
-    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kk = 0; kk < kHalf; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[kk], qreg[kk], acc, 0, 0, 0);
-    const int remain = len - tok0;  // valid token rows in this tile (wave-uniform)
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const int row = (g & 3) + 8 * (g >> 2) + 4 * h;  // C/D map of the 32x32 MFMA
-      float v = acc[g];
-      if (remain < 32 && row >= remain) v = -FLT_MAX;
-      best = fmaxf(best, v);
-    }
+    ms4f af[2][8];  // rows past the document end are clamped here and masked in ms_tile
+    ms_load_frag(D, t_lo + tok0, t_hi - 1, i16, kq, false, af);
+    ms_tile(af, qf, kq, len - tok0, best);
   }
-  // the other half of the wave holds the complementary token rows of the same q-token
-  float other = __uint_as_float(lane_xor<32>(__float_as_uint(best)));
-  best = fmaxf(best, other);
-  float contrib = (h == 0 && r < q_len) ? best : 0.f;
-  float total = ms_wave_sum(contrib);
+  const float total = ms_finish(best, i16, kq, q_len);
   if (lane == 0) scores[(size_t)qi * n_docs + doc] = total;
 }
 
@@ -118,8 +148,9 @@ __global__ __launch_bounds__(256) void maxsim_scores_kernel(const float* __restr
 constexpr int kMsQ = 8;     // queries (waves) per block
 constexpr int kMsDocs = 8;  // documents per block
 
-// LDS tile: token row j (0..31) at byte j*512, its 16-B slot s (0..31) at s ^ (j & 15): a
-// ds_read_b128 lane group (16 rows, same logical slot) covers 16 distinct bank quads; a
+// LDS tile: token row j (0..31) at byte j*512, its 16-B slot s (0..31) at s ^ (j & 15).  A
+// ds_read_b128 lane group holds 16 distinct rows, eight reading slot 4t + kq and eight
+// 4t + (kq ^ 1): the XOR maps those two sets onto disjoint bank quads (conflict-free); a
 // staging write of one row (32 consecutive threads) covers the row's 512 B.
 __device__ __forceinline__ int ms_tile_off(int row, int slot) { return row * 512 + ((slot ^ (row & 15)) << 4); }
 
@@ -131,19 +162,21 @@ __global__ __launch_bounds__(kMsQ * 64) void maxsim_scores_blocked_kernel(const 
   __shared__ __attribute__((aligned(16))) unsigned char tile[2][32 * 512];
   typedef float v4f __attribute__((ext_vector_type(4)));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, h = lane >> 5;
+  const int i16 = lane & 15, kq = lane >> 4;
   const int qi = blockIdx.x * kMsQ + wave;
   const bool live = qi < nq;
   const long d0 = (long)blockIdx.y * kMsDocs;
   long d1 = d0 + kMsDocs;
   if (d1 > n_docs) d1 = n_docs;
 
-  float qreg[kHalf];
-  if (live && r < q_len) {
-    load_half_row(Q + ((size_t)qi * q_len + r) * kDim + h * kHalf, qreg);
+  ms4f qf[2][8];
+  if (live) {
+    ms_load_frag(Q + (size_t)qi * q_len * kDim, 0, q_len - 1, i16, kq, true, qf);
   } else {
 #pragma unroll
-    for (int m = 0; m < kHalf; ++m) qreg[m] = 0.f;
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) qf[b][t] = ms4f{0.f, 0.f, 0.f, 0.f};
   }
 
   // loader role: two 16-B pieces per thread and tile (elements tid and tid + 512 of 1024)
@@ -166,7 +199,7 @@ __global__ __launch_bounds__(kMsQ * 64) void maxsim_scores_blocked_kernel(const 
   AMDR_MS_STAGE(0)
   __syncthreads();
   int buf = 0;
-  float best = -FLT_MAX;
+  float best[2] = {-FLT_MAX, -FLT_MAX};
   (void)n_tokens;
   while (true) {
     // coordinates of the next tile (wave-uniform)
@@ -185,32 +218,17 @@ __global__ __launch_bounds__(kMsQ * 64) void maxsim_scores_blocked_kernel(const 
     const bool has_next = ndoc < d1;
     if (has_next) { AMDR_MS_LOAD(nt_lo, nlen, ntok) }
 
-    float areg[kHalf];
+    ms4f af[2][8];
 #pragma unroll
-    for (int m = 0; m < kHalf / 4; ++m) {
-      const v4f v = *reinterpret_cast<const v4f*>(tile[buf] + ms_tile_off(r, 16 * h + m));
-      areg[4 * m + 0] = v.x;
-      areg[4 * m + 1] = v.y;
-      areg[4 * m + 2] = v.z;
-      areg[4 * m + 3] = v.w;
-    }
-    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-    for (int kk = 0; kk < kHalf; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[kk], qreg[kk], acc, 0, 0, 0);
-    const int remain = len - tok0;
-#pragma unroll
-    for (int gi = 0; gi < 16; ++gi) {
-      const int row = (gi & 3) + 8 * (gi >> 2) + 4 * h;
-      float v = acc[gi];
-      if (remain < 32 && row >= remain) v = -FLT_MAX;
-      best = fmaxf(best, v);
-    }
+      for (int t = 0; t < 8; ++t)
+        af[b][t] = *reinterpret_cast<const ms4f*>(tile[buf] + ms_tile_off(16 * b + i16, 4 * t + kq));
+    ms_tile(af, qf, kq, len - tok0, best);
     if (ntok == 0) {  // last tile of this document
-      const float other = __uint_as_float(lane_xor<32>(__float_as_uint(best)));
-      const float b2 = fmaxf(best, other);
-      const float total = ms_wave_sum((h == 0 && r < q_len) ? b2 : 0.f);
+      const float total = ms_finish(best, i16, kq, q_len);
       if (live && lane == 0) scores[(size_t)qi * n_docs + doc] = total;
-      best = -FLT_MAX;
+      best[0] = best[1] = -FLT_MAX;
     }
     if (!has_next) break;
     AMDR_MS_STAGE(buf ^ 1)
