@@ -359,10 +359,12 @@ __device__ __forceinline__ int wave_allmin_i32(int x) {
   return x;
 }
 
-template <class C>
-__device__ inline C wave_sort64_desc(C v, int lane) {
+// Bitonic network across the lanes: sorts every aligned group of N lanes (N = 16, 32 or 64)
+// descending; exchange steps never reach past the group.
+template <class C, int N>
+__device__ inline C wave_sortN_desc(C v, int lane) {
 #pragma unroll
-  for (int size = 2; size <= 64; size <<= 1) {
+  for (int size = 2; size <= N; size <<= 1) {
 #pragma unroll
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
       const C o = wave_xchg_xor(v, stride);
@@ -372,6 +374,10 @@ __device__ inline C wave_sort64_desc(C v, int lane) {
     }
   }
   return v;
+}
+template <class C>
+__device__ inline C wave_sort64_desc(C v, int lane) {
+  return wave_sortN_desc<C, 64>(v, lane);
 }
 
 template <class C, int V>
@@ -396,7 +402,13 @@ __device__ inline int wave_select_small(const C (&keys)[V], int k, C* scratch /*
   }
   wave_lds_fence();
   C c = (lane < cnt) ? scratch[lane] : C::pad();
-  c = wave_sort64_desc(c, lane);
+  // the survivors sit in lanes 0 .. cnt-1 (a few more than k): sort only the lane group that holds them
+  if (cnt <= 16)
+    c = wave_sortN_desc<C, 16>(c, lane);
+  else if (cnt <= 32)
+    c = wave_sortN_desc<C, 32>(c, lane);
+  else
+    c = wave_sortN_desc<C, 64>(c, lane);
   wave_lds_fence();
   if (lane < k) out_sorted[lane] = c;
   wave_lds_fence();
