@@ -30,7 +30,7 @@ import struct
 import sys
 import types
 from pathlib import Path
-from typing import Any, Dict, List, Sequence, Tuple
+from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -216,6 +216,9 @@ def read_bm25_pickle(path: Path) -> Tuple[BM25Okapi, List[LawChunk]]:
     for attr in ("k1", "b", "corpus_size", "avgdl", "doc_freqs", "idf", "doc_len"):
         if not hasattr(bm25, attr):
             raise RuntimeError(f"[BM25] index object lacks attribute '{attr}': {path}")
+    # which segmenter produced the index tokens (written by this build only; a reference-built
+    # pickle has no such key: English regex words or jieba, bm25_builder.py:39-44)
+    bm25.__dict__["_tokenizer_id"] = obj.get("tokenizer") if isinstance(obj.get("tokenizer"), str) else None
     chunks: List[LawChunk] = []
     for c in obj.get("chunks", []):
         if isinstance(c, LawChunk):
@@ -242,9 +245,10 @@ class _BM25Pickler(pickle.Pickler):
         return NotImplemented
 
 
-def write_bm25_pickle(path: Path, bm25: BM25Okapi, chunks: Sequence[LawChunk]) -> None:
+def write_bm25_pickle(path: Path, bm25: BM25Okapi, chunks: Sequence[LawChunk], tokenizer: Optional[str] = None) -> None:
     """bm25_builder.py:46-51 payload, atomically replaced
-    (incremental_bm25_builder.py:76-79)."""
+    (incremental_bm25_builder.py:76-79).  `tokenizer` (id of the segmenter that produced the
+    index tokens, text.tokenizer_id) is stored as a third key the reference's loader ignores."""
     path = Path(path)
     path.parent.mkdir(parents=True, exist_ok=True)
     real = sys.modules.get("rank_bm25")
@@ -259,7 +263,10 @@ def write_bm25_pickle(path: Path, bm25: BM25Okapi, chunks: Sequence[LawChunk]) -
         sys.modules["rank_bm25"] = shim
     try:
         buf = io.BytesIO()
-        _BM25Pickler(buf, proxy).dump({"bm25": bm25, "chunks": [c.model_dump() for c in chunks]})
+        payload = {"bm25": bm25, "chunks": [c.model_dump() for c in chunks]}
+        if tokenizer:
+            payload["tokenizer"] = str(tokenizer)
+        _BM25Pickler(buf, proxy).dump(payload)
     finally:
         if shim is not None:
             if real is not None:

@@ -63,7 +63,7 @@ class BM25Okapi:
     # -- device side --------------------------------------------------------
     def __getstate__(self):
         st = dict(self.__dict__)
-        for k in ("_vocab", "_gpu", "_gpu_device"):
+        for k in ("_vocab", "_gpu", "_gpu_device", "_tokenizer_id"):
             st.pop(k, None)
         return st
 

@@ -75,6 +75,8 @@ class RetrievalConfig:
     # --- build-specific knobs (no reference counterpart) ---
     device: int = 0                      # HIP device ordinal of this process
     encoder_backend: str = "auto"        # "auto" | "transformers" | "hashing" (deterministic stand-in)
+    zh_tokenizer: str = "jieba"          # "jieba" (raises if Han text meets no segmenter) | "char" (explicit
+                                         # opt-in to the inexact one-character stand-in, text.py)
 
 
 @dataclass

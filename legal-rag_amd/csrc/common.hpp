@@ -79,4 +79,15 @@ int dense_mfma_launch_scores(const DenseMfmaPlan& p, const float* X, long n, int
 int dense_mfma_launch_topk(const DenseMfmaPlan& p, const float* S, long n, int nq, int k, void* part,
                            float* fin_scores, int64_t* fin_ids, hipStream_t st);
 
+
+// ---- long-batch dense path: dense_panel.hip (panel of chunk rows shared by a block through LDS) ----
+struct DensePanelPlan {
+  int parts, base, rem, nb, m_tiles, gm, waves;
+  size_t lds;
+};
+bool dense_panel_supported(long n, int d, int nq);
+void dense_panel_plan(long n, int d, int nq, DensePanelPlan* p);
+int dense_panel_launch_scores(const DensePanelPlan& p, const float* X, long n, int d, const float* Q, int nq, long ldS,
+                              float* S, hipStream_t st);
+
 }  // namespace amdr

@@ -397,6 +397,12 @@ int run_search_batched(amdr_dense* h, const float* Q_dev, int nq, int k, float* 
       hipLaunchKernelGGL(dense_all_scores_kernel, dim3(ceil_div((long)m * h->n, kWaves)), dim3(256), 0, st, h->X,
                          (long)h->n, h->d, Q_dev + (size_t)q0 * h->d, m, p.ld, h->smat.as<float>());
       AMDR_HIP(hipGetLastError());
+    } else if (dense_panel_supported((long)h->n, h->d, m)) {
+      DensePanelPlan pp;
+      dense_panel_plan((long)h->n, h->d, m, &pp);
+      rc = dense_panel_launch_scores(pp, h->X, (long)h->n, h->d, Q_dev + (size_t)q0 * h->d, m, p.ld,
+                                     h->smat.as<float>(), st);
+      if (rc) return rc;
     } else {
       rc = dense_mfma_launch_scores(p, h->X, (long)h->n, h->d, Q_dev + (size_t)q0 * h->d, m, h->smat.as<float>(), st);
       if (rc) return rc;

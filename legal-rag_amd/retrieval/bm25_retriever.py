@@ -6,16 +6,27 @@ jieba.cut WITHOUT lower-casing (:73), scores every document with Okapi BM25 and
 returns the first top_k of a stable descending sort — zero-score documents
 included, ties in ascending document order (:74-76).  Scoring and ranking run in
 the HIP kernel (csrc/bm25.hip), bit-identical to rank_bm25's float64 numpy
-expression."""
+expression.
+
+Tokenisation is never silently inexact (text.py): a Han query without a
+segmenter raises `text.ZhTokenizerUnavailable` unless cfg.retrieval.zh_tokenizer
+= "char" opts in (then `zh_exact` is False and the hybrid layer stamps it into
+score_breakdown); `search(..., tokens=)` takes the caller's own tokens; an index
+whose recorded tokenizer is "char" is queried in the same mode so that index and
+query tokens stay consistent."""
 from __future__ import annotations
 
 import threading
 from pathlib import Path
-from typing import List, Tuple
+import logging
+from typing import List, Optional, Sequence, Tuple
 
 from .. import artifacts, text
 from ..bm25_model import BM25Okapi
 from ..schemas import LawChunk
+
+
+logger = logging.getLogger(__name__)
 
 
 class BM25Retriever:
@@ -29,6 +40,8 @@ class BM25Retriever:
         self.bm25: BM25Okapi | None = None
         self.chunks: List[LawChunk] = []
         self._lock = threading.Lock()
+        self.index_tokenizer: Optional[str] = None  # id recorded in bm25.pkl (None: reference-built)
+        self.zh_exact = True                          # False once a query was tokenised by the stand-in
 
     def load(self) -> None:
         if not self.bm25_path.exists():
@@ -45,13 +58,30 @@ class BM25Retriever:
             bm25.gpu(self.device_index)  # upload CSR postings now, not on the first query
             self.bm25 = bm25
             self.chunks = chunks
+            self.index_tokenizer = bm25.__dict__.get("_tokenizer_id")
+            if self.index_tokenizer == "char":
+                self.zh_exact = False
+                logger.warning("[BM25] %s was built with the one-character stand-in tokenizer: results differ "
+                               "from a jieba-built index (zh_exact=False)", self.bm25_path)
             self._loaded = True
             self._bm25_mtime = current_mtime
 
-    def search(self, query: str, top_k: int) -> List[Tuple[LawChunk, float]]:
+    def tokenize_query(self, query: str) -> List[str]:
+        """bm25_retriever.py:73 — jieba.cut, not lower-cased.  Mode "char" when the index was built
+        that way or the config opts in; otherwise a Han query without a segmenter raises."""
+        mode = "char" if self.index_tokenizer == "char" else text.cfg_mode(self.cfg)
+        if self.index_tokenizer == "char" and text.contains_han(query):
+            toks = text.jieba_cut_restated(query)  # same stand-in as the index, whatever is installed
+        else:
+            toks = text.jieba_cut(query, mode)
+        if text.contains_han(query) and (self.index_tokenizer == "char" or not text.zh_exact()):
+            self.zh_exact = False
+        return toks
+
+    def search(self, query: str, top_k: int, tokens: Optional[Sequence[str]] = None) -> List[Tuple[LawChunk, float]]:
         self.load()
         assert self.bm25 is not None
-        tokens = text.jieba_cut(query)
+        tokens = list(tokens) if tokens is not None else self.tokenize_query(query)
         k = int(top_k)
         if k <= 0:
             return []

@@ -41,7 +41,9 @@ class IncrementalBM25Builder:
             logger.info("[bm25] no new chunks to add: incoming=%d", len(batch))
             return 0
         corpus = kept + fresh
+        mode = text.cfg_mode(self.cfg)
         artifacts.write_bm25_pickle(Path(self.cfg.retrieval.bm25_index_file),
-                                    BM25Okapi([text.jieba_cut(c.text) for c in corpus]), corpus)
+                                    BM25Okapi([text.jieba_cut(c.text, mode) for c in corpus]), corpus,
+                                    tokenizer=text.tokenizer_id(mode))
         logger.info("[bm25] incremental add done: added=%d total=%d", len(fresh), len(corpus))
         return len(fresh)

@@ -155,14 +155,17 @@ class HybridRetriever:
             h.score_breakdown = {"channel": ["dense"], "dense_raw": float(h.score)}
         return hits
 
-    def search_bm25(self, question: str, top_k: int = 10) -> List[RetrievalHit]:
+    def search_bm25(self, question: str, top_k: int = 10, tokens: Optional[Sequence[str]] = None) -> List[RetrievalHit]:
+        """`tokens`: the caller's own segmentation of `question` (exact path without jieba)."""
         top_k = max(1, int(top_k))
         hits = [RetrievalHit(chunk=c, score=float(s), rank=i, source="retriever",
                              score_breakdown={"channel": ["bm25"], "bm25_raw": float(s)})
-                for i, (c, s) in enumerate(self.bm25.search(question, top_k), start=1)]
+                for i, (c, s) in enumerate(self.bm25.search(question, top_k, tokens=tokens), start=1)]
         hits.sort(key=lambda h: float(h.score), reverse=True)
         for i, h in enumerate(hits, start=1):
             h.rank = i
+            if not self.bm25.zh_exact:  # stand-in tokenizer ran: never unmarked (text.py)
+                h.score_breakdown["zh_exact"] = False
         return hits
 
     def search_colbert(self, question: str, top_k: int = 10) -> List[RetrievalHit]:
@@ -386,7 +389,7 @@ class HybridRetriever:
         eng = HybridEngine(self.dense.store.index.native, self.bm25.bm25.gpu(dev),
                            self.colbert._searcher if self.colbert is not None else None, device=dev)
         Q = self.dense.store._embed(list(questions), is_query=True)
-        tids = [self.bm25.bm25.term_ids(text.jieba_cut(q)) for q in questions]
+        tids = [self.bm25.bm25.term_ids(self.bm25.tokenize_query(q)) for q in questions]
         qt, qp = _native.BM25Index.pack_queries(tids)
         q_tok = None
         if self.colbert is not None:

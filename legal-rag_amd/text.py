@@ -17,13 +17,26 @@ published algorithm: jieba/__init__.py `cut`/`__cut_DAG`, finalseg `cut`):
   2. inside a block made of single-character DAG steps the whole buffer goes
      through finalseg.cut: runs matching [a-zA-Z0-9]+(?:\\.\\d+)?%? are one token
      each, and each maximal run of the remaining characters is one token.
-Han runs cannot be segmented without dict.txt: they are emitted one character
-per token and `ZH_EXACT` is False — zh BM25 parity is then UNPINNED.
+Han runs cannot be segmented without dict.txt.  That case is never silent:
+  * default: `jieba_cut` raises `ZhTokenizerUnavailable` when the text holds Han
+    characters and neither jieba nor a registered tokenizer is available;
+  * `register_tokenizer(fn, name)` plugs in an exact segmenter (a caller that
+    has jieba elsewhere, or any jieba-compatible callable);
+  * pre-tokenised entry points (`build_bm25_index(..., tokens=)`,
+    `BM25Retriever.search(..., tokens=)`) bypass tokenisation altogether;
+  * explicit opt-in to the inexact one-character-per-token stand-in:
+    `cfg.retrieval.zh_tokenizer = "char"` (or LEGALRAG_ZH_TOKENIZER=char, or
+    `mode="char"`): a WARNING is logged once, the index records tokenizer id
+    "char" and every consumer reports `zh_exact: False`.
 """
 from __future__ import annotations
 
+import logging
+import os
 import re
-from typing import List
+from typing import Callable, List, Optional
+
+logger = logging.getLogger(__name__)
 
 try:  # pragma: no cover - not installed in the build container
     import jieba as _jieba
@@ -32,7 +45,45 @@ except Exception:  # noqa: BLE001
     _jieba = None
     HAVE_JIEBA = False
 
-ZH_EXACT = HAVE_JIEBA
+
+class ZhTokenizerUnavailable(RuntimeError):
+    """Han text needs jieba's dictionary segmentation and none is available."""
+
+
+_custom_cut: Optional[Callable[[str], List[str]]] = None
+_custom_name: Optional[str] = None
+_warned_char = False
+
+
+def register_tokenizer(fn: Optional[Callable[[str], List[str]]], name: str = "custom") -> None:
+    """Use `fn(sentence) -> tokens` wherever the reference calls jieba.cut (None removes it)."""
+    global _custom_cut, _custom_name
+    _custom_cut, _custom_name = fn, (name if fn is not None else None)
+
+
+def zh_exact() -> bool:
+    """True when Han text is segmented by jieba (or a registered exact tokenizer)."""
+    return HAVE_JIEBA or _custom_cut is not None
+
+
+def tokenizer_id(mode: Optional[str] = None) -> str:
+    """Id recorded in bm25.pkl next to the index: which segmenter produced its tokens."""
+    if _custom_cut is not None:
+        return str(_custom_name)
+    if HAVE_JIEBA:
+        return "jieba"
+    return "char" if resolve_mode(mode) == "char" else "jieba-restated-ascii"
+
+
+def resolve_mode(mode: Optional[str]) -> str:
+    m = (mode or os.environ.get("LEGALRAG_ZH_TOKENIZER") or "jieba").strip().lower()
+    return "char" if m == "char" else "jieba"
+
+
+def cfg_mode(cfg) -> Optional[str]:
+    """`cfg.retrieval.zh_tokenizer` if the (duck-typed) config has it."""
+    return getattr(getattr(cfg, "retrieval", None), "zh_tokenizer", None)
+
 
 _EN_INDEX_RE = re.compile(r"[A-Za-z0-9]+(?:'[A-Za-z0-9]+)?")
 _RE_BLOCK = re.compile(r"([一-鿕a-zA-Z0-9+#&\._%\-]+)", re.U)
@@ -103,10 +154,33 @@ def jieba_cut_restated(sentence: str) -> List[str]:
     return out
 
 
-def jieba_cut(sentence: str) -> List[str]:
-    """`list(jieba.cut(sentence))` — the wheel if present, else the restatement."""
+def contains_han(sentence: str) -> bool:
+    return _RE_HAN.search(sentence) is not None
+
+
+def jieba_cut(sentence: str, mode: Optional[str] = None) -> List[str]:
+    """`list(jieba.cut(sentence))`: a registered tokenizer, else the wheel, else — for text
+    without Han characters only — the exact restatement.  Han text without a segmenter raises
+    ZhTokenizerUnavailable unless the one-character stand-in was chosen explicitly (`mode` /
+    LEGALRAG_ZH_TOKENIZER = "char"); that choice is logged once."""
+    global _warned_char
+    if _custom_cut is not None:
+        return list(_custom_cut(sentence))
     if HAVE_JIEBA:
         return list(_jieba.cut(sentence))
+    if not contains_han(sentence):
+        return jieba_cut_restated(sentence)
+    if resolve_mode(mode) != "char":
+        raise ZhTokenizerUnavailable(
+            "text contains Han characters but jieba is not importable: BM25 tokens would differ from the "
+            "reference (bm25_builder.py:43, bm25_retriever.py:73). Install jieba, call "
+            "legal_rag_amd.text.register_tokenizer(fn), pass pre-tokenised input (tokens=...), or opt in to the "
+            "inexact one-character-per-token stand-in with cfg.retrieval.zh_tokenizer='char' / "
+            "LEGALRAG_ZH_TOKENIZER=char")
+    if not _warned_char:
+        _warned_char = True
+        logger.warning("[BM25] jieba is not importable: Han text is tokenised one character per token "
+                       "(zh_tokenizer='char'). zh BM25 results differ from the reference; zh_exact=False")
     return jieba_cut_restated(sentence)
 
 

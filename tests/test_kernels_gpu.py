@@ -124,6 +124,40 @@ def test_dense_orientations_agree_bitwise(nat, monkeypatch):
     assert np.array_equal(out["n"][0], out["t"][0])
 
 
+@pytest.mark.parametrize("parts", [None, "lo", "hi"])
+def test_dense_panel_kernel_shapes(nat, parts, monkeypatch):
+    """Long-batch form (dense_panel.hip: a block shares a panel of chunk rows through LDS): partial
+    row blocks, partial query tiles, panels of 1..8 row blocks, parts of unequal size; the cut into
+    parts pinned to its smallest and to a large count as well as the planner's choice."""
+    monkeypatch.setenv("AMDR_DENSE_PANEL", "1")
+    rng = np.random.default_rng(79)
+    for n, d, nq, k in [(591, 768, 2500, 10), (100, 64, 700, 5), (1999, 384, 1030, 20), (33, 1024, 300, 50),
+                        (40, 832, 333, 7), (1, 128, 140, 3), (65, 192, 97, 80), (4097, 256, 128, 10),
+                        (1260, 768, 129, 10), (17, 64, 5, 4), (16, 64, 33, 16), (130, 320, 1000, 256)]:
+        nb = (n + 15) // 16
+        pmin = (nb + 7) // 8
+        if parts == "lo":
+            monkeypatch.setenv("AMDR_PANEL_PARTS", str(pmin))
+        elif parts == "hi":
+            monkeypatch.setenv("AMDR_PANEL_PARTS", str(min(nb, 2 * pmin + 3)))
+        check_dense(nat, unit_rows(rng, n, d), unit_rows(rng, nq, d), k)
+
+
+def test_dense_panel_agrees_bitwise_with_tiles(nat, monkeypatch):
+    """The panel kernel and the 32x32-tile kernel feed the matrix pipe the same k order per
+    (query, row): identical bits, identical ids."""
+    rng = np.random.default_rng(80)
+    X, Q = unit_rows(rng, 591, 768), unit_rows(rng, 1500, 768)
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("AMDR_DENSE_PANEL", flag)
+        idx = nat.DenseIndex(X)
+        out[flag] = idx.search(Q, 10)
+        idx.close()
+    assert np.array_equal(out["0"][1], out["1"][1])
+    assert np.array_equal(out["0"][0], out["1"][0])
+
+
 def test_dense_golden_fixture(nat):
     """Seeded fixture of SURVEY.md §8c(3): X[4096,768], Q[16,768], rng(0)."""
     g = np.load(str(__import__("conftest").GOLDEN / "dense_flatip_golden.npz"))
