@@ -45,6 +45,11 @@ __device__ __forceinline__ int panel_off(int row, int slot) { return row * 128 +
 // One (32 queries per wave) x (NBP x 16 rows) tile.  NBE = row blocks the panel buffers are
 // sized and filled for (NBP rounded up so that every wave issues the same number of DMA
 // pieces: the surplus rows repeat the last valid row and are never multiplied).
+// Tried and dropped (same-box A/B, scripts/ab_dense_panel.py): (i) ONE LDS buffer for the wave's
+// own query chunk (fragments to registers first, then the next DMA over them: 40 KiB per block,
+// four blocks per CU instead of two) — 3-8 % slower at every shape; (ii) fragment reads pinned one
+// half-chunk ahead of their MFMAs across the barrier, DMA two chunks ahead spread between the MFMA
+// groups (sched_barrier-pinned phases) — 2-9 % slower than hipcc's own schedule of this loop.
 template <int NBP, int NBE, int WAVES>
 __device__ __forceinline__ void panel_tile(const float* __restrict__ X, long n, const float* __restrict__ Q, int nq,
                                            int d, long row0, int q0w, long ldS, float* __restrict__ S,
@@ -52,8 +57,8 @@ __device__ __forceinline__ void panel_tile(const float* __restrict__ X, long n, 
   constexpr int XBYTES = NBE * 16 * 128;          // one panel chunk
   constexpr int PPW = 2 * NBE / WAVES;            // panel DMA pieces per wave per chunk
   static_assert((2 * NBE) % WAVES == 0, "panel pieces must divide over the waves");
-  unsigned char* xs = smem;                                   // [2][XBYTES]
-  unsigned char* qs = smem + 2 * XBYTES + wave * 2 * 4096;    // [2][4096], private to the wave
+  unsigned char* xs = smem;                                  // [2][XBYTES]
+  unsigned char* qs = smem + 2 * XBYTES + wave * 2 * 4096;   // [2][4096], private to the wave
   const int i16 = lane & 15, kq = lane >> 4;
   const int prow = lane >> 3, pslot = lane & 7;  // DMA role: row in the 8-row piece, PHYSICAL slot
   const int nch = d / kPanelKC;
@@ -86,39 +91,58 @@ __device__ __forceinline__ void panel_tile(const float* __restrict__ X, long n, 
 #pragma unroll
     for (int bq = 0; bq < 2; ++bq) acc[b][bq] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#define AMDR_PANEL_ISSUE(C, BUF)                                                                         \
+// DMA piece J of chunk C (J < PPW: this wave's share of the panel; then its 4 query pieces)
+#define AMDR_PANEL_PIECE(C, BUF, J)                                                                      \
   {                                                                                                      \
-    _Pragma("unroll") for (int j = 0; j < PPW; ++j) __builtin_amdgcn_global_load_lds(                    \
-        AMDR_GPTR(xp[j] + (size_t)(C) * kPanelKC), AMDR_LPTR(xs + (BUF) * XBYTES + (wave + WAVES * j) * 1024), 16, 0, 0); \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds(                      \
-        AMDR_GPTR(qp[j] + (size_t)(C) * kPanelKC), AMDR_LPTR(qs + (BUF) * 4096 + j * 1024), 16, 0, 0);   \
+    if ((J) < PPW)                                                                                       \
+      __builtin_amdgcn_global_load_lds(AMDR_GPTR(xp[(J) < PPW ? (J) : 0] + (size_t)(C) * kPanelKC),      \
+                                       AMDR_LPTR(xs + (BUF) * XBYTES + (wave + WAVES * (J)) * 1024), 16, 0, 0); \
+    else                                                                                                 \
+      __builtin_amdgcn_global_load_lds(AMDR_GPTR(qp[(J) >= PPW ? (J) - PPW : 0] + (size_t)(C) * kPanelKC), \
+                                       AMDR_LPTR(qs + (BUF) * 4096 + ((J) - PPW) * 1024), 16, 0, 0);     \
   }
+#define AMDR_PANEL_ISSUE(C, BUF, J0, J1) \
+  { _Pragma("unroll") for (int j_ = (J0); j_ < (J1); ++j_) AMDR_PANEL_PIECE(C, BUF, j_) }
+#define AMDR_PANEL_READ(XF, QF, BUF, U)                                                                  \
+  {                                                                                                      \
+    _Pragma("unroll") for (int bq = 0; bq < 2; ++bq) QF[bq] =                                            \
+        *reinterpret_cast<const f32x4*>(qs + (BUF) * 4096 + bq * 2048 + foff[U]);                        \
+    _Pragma("unroll") for (int b = 0; b < NBP; ++b) XF[b] =                                              \
+        *reinterpret_cast<const f32x4*>(xs + (BUF) * XBYTES + b * 2048 + foff[U]);                       \
+  }
+#define AMDR_PANEL_MFMA(XF, QF, E0, E1)                                                                  \
+  _Pragma("unroll") for (int e = (E0); e < (E1); ++e) _Pragma("unroll") for (int b = 0; b < NBP; ++b)    \
+      _Pragma("unroll") for (int bq = 0; bq < 2; ++bq) acc[b][bq] =                                      \
+          __builtin_amdgcn_mfma_f32_16x16x4f32(XF[b][e], QF[bq][e], acc[b][bq], 0, 0, 0);
 
-  AMDR_PANEL_ISSUE(0, 0)
-  __syncthreads();  // vmcnt(0) + barrier: chunk 0 is in LDS for every wave
-  for (int c = 0; c < nch; ++c) {
-    const int buf = c & 1;
-    if (c + 1 < nch) AMDR_PANEL_ISSUE(c + 1, buf ^ 1)
-    const unsigned char* xb = xs + buf * XBYTES;
-    const unsigned char* qb = qs + buf * 4096;
+  constexpr int NP = PPW + 4;  // DMA pieces per wave per chunk
+  // An LDS-DMA is ordered for a later ds_read only by the ISSUING wave's vmcnt wait followed by a
+  // barrier the reader has passed.  hipcc puts that wait in front of a __syncthreads() only when it
+  // sees the DMA in straight-line code before it (it did not once the DMA sat behind the loop's
+  // back edge), so the wait is written out.
+#define AMDR_PANEL_PUBLISH()                          \
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    \
+  __syncthreads();
+  {
+    AMDR_PANEL_ISSUE(0, 0, 0, NP)
+    AMDR_PANEL_PUBLISH()  // chunk 0 is in LDS for every wave
+    for (int c = 0; c < nch; ++c) {
+      const int buf = c & 1;
+      if (c + 1 < nch) AMDR_PANEL_ISSUE(c + 1, buf ^ 1, 0, NP)
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      f32x4 qf[2], xf[NBP];
-#pragma unroll
-      for (int bq = 0; bq < 2; ++bq) qf[bq] = *reinterpret_cast<const f32x4*>(qb + bq * 2048 + foff[u]);
-#pragma unroll
-      for (int b = 0; b < NBP; ++b) xf[b] = *reinterpret_cast<const f32x4*>(xb + b * 2048 + foff[u]);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int b = 0; b < NBP; ++b)
-#pragma unroll
-          for (int bq = 0; bq < 2; ++bq)
-            acc[b][bq] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[b][e], qf[bq][e], acc[b][bq], 0, 0, 0);
+      for (int u = 0; u < 2; ++u) {
+        f32x4 xf[NBP], qf[2];
+        AMDR_PANEL_READ(xf, qf, buf, u)
+        AMDR_PANEL_MFMA(xf, qf, 0, 4)
+      }
+      AMDR_PANEL_PUBLISH()  // every wave has read chunk c; chunk c+1 has landed
     }
-    __syncthreads();  // every wave has read chunk c; chunk c+1 has landed
   }
+#undef AMDR_PANEL_PIECE
+#undef AMDR_PANEL_PUBLISH
 #undef AMDR_PANEL_ISSUE
+#undef AMDR_PANEL_READ
+#undef AMDR_PANEL_MFMA
   // acc[b][bq][r] = <X[row0 + 16 b + 4 kq + r], Q[q0w + 16 bq + i16]>
 #pragma unroll
   for (int bq = 0; bq < 2; ++bq) {
@@ -183,10 +207,13 @@ bool dense_panel_supported(long n, int d, int nq) {
 void dense_panel_plan(long n, int d, int nq, DensePanelPlan* p) {
   const long nb_total = (n + 15) / 16;
   const int m_tiles = ceil_div(nq, 32 * kPanelWaves);
-  // parts: every part has NB or NB - 1 row blocks, NB <= kPanelNBMax.  Blocks are spread over
-  // 256 CUs; a CU's time ~ (blocks it gets) x (row blocks per part + fixed cost per block).
+  // parts: every part has NB or NB - 1 row blocks, NB <= kPanelNBMax; blocks = m_tiles x parts are
+  // dealt over 256 CUs, two resident per CU (LDS).  Fitted on measured launches (591 / 1260 / 1851
+  // rows x 9 344 ... 37 376 queries, profiles/r02_dense_panel_ab.md): a block costs ~(row blocks +
+  // 0.2); a CU works its blocks in pairs, and a last block left alone on its CU runs at 0.6 of the
+  // paired throughput — so the cut is chosen to give every CU an even number of blocks.
   long pmin = (nb_total + kPanelNBMax - 1) / kPanelNBMax;
-  long pmax = nb_total < 2 * pmin + 8 ? nb_total : 2 * pmin + 8;
+  long pmax = nb_total < 4 * pmin + 8 ? nb_total : 4 * pmin + 8;
   if (pmax < pmin) pmax = pmin;
   long best_p = pmin;
   double best = 1e300;
@@ -195,8 +222,11 @@ void dense_panel_plan(long n, int d, int nq, DensePanelPlan* p) {
     best_p = atol(pin);
   } else {
     for (long q = pmin; q <= pmax; ++q) {
-      const double per_cu = (double)(((long)m_tiles * q + 255) / 256);
-      const double est = per_cu * ((double)nb_total / (double)q + 0.5);
+      const double bpc = (double)m_tiles * (double)q / 256.0;
+      const long top = (long)(bpc + 0.999999);
+      double units = (double)top;
+      if (top & 1) units += 0.6 * (top > bpc ? bpc - (double)(top - 1) : 1.0);
+      const double est = units * ((double)nb_total / (double)q + 0.2);
       if (est < best * (1.0 - 1e-9)) {
         best = est;
         best_p = q;
@@ -215,16 +245,15 @@ void dense_panel_plan(long n, int d, int nq, DensePanelPlan* p) {
 
 template <int NB>
 static int launch_panel(const DensePanelPlan& p, const float* X, long n, int d, const float* Q, int nq, long ldS,
-                        float* S, hipStream_t st) {
+                          float* S, hipStream_t st) {
   // > 64 KiB of dynamic LDS needs the opt-in; it is a per-device function attribute, cheap to set
   AMDR_HIP(hipFuncSetAttribute((const void*)dense_panel_scores_kernel<NB, kPanelWaves>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel_lds(NB, kPanelWaves)));
-  hipLaunchKernelGGL((dense_panel_scores_kernel<NB, kPanelWaves>), dim3(p.m_tiles * p.parts), dim3(kPanelWaves * 64),
-                     p.lds, st, X, n, Q, nq, d, p.parts, p.base, p.rem, p.m_tiles, p.gm, ldS, S);
+  hipLaunchKernelGGL((dense_panel_scores_kernel<NB, kPanelWaves>), dim3(p.m_tiles * p.parts),
+                     dim3(kPanelWaves * 64), p.lds, st, X, n, Q, nq, d, p.parts, p.base, p.rem, p.m_tiles, p.gm, ldS, S);
   AMDR_HIP(hipGetLastError());
   return AMDR_OK;
 }
-
 int dense_panel_launch_scores(const DensePanelPlan& p, const float* X, long n, int d, const float* Q, int nq,
                               long ldS, float* S, hipStream_t st) {
   switch (p.nb) {

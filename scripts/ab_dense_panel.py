@@ -44,9 +44,10 @@ def main():
     nb = (n + 15) // 16
     pmin = (nb + 7) // 8
     variants = [("tile32", {"AMDR_DENSE_PANEL": "0"}), ("panel", {"AMDR_DENSE_PANEL": "1"})]
-    for p in sorted(set([pmin, pmin + 1, pmin + 2, pmin + 3, (nb + 3) // 4])):
-        if pmin <= p <= nb:
-            variants.append((f"panel/p{p}", {"AMDR_DENSE_PANEL": "1", "AMDR_PANEL_PARTS": str(p)}))
+    for qb in ("0",):
+        for p in sorted(set([pmin, pmin + 1, pmin + 2, pmin + 3, pmin + 4, (nb + 4) // 5, (nb + 3) // 4, (nb + 2) // 3])):
+            if pmin <= p <= nb:
+                variants.append((f"panel/p{p}", {"AMDR_DENSE_PANEL": "1", "AMDR_PANEL_PARTS": str(p)}))
     ref = (Q[:128] @ X.T)
     top = torch.topk(ref, min(k, n), dim=1).indices.cpu().numpy()
     times = {name: [] for name, _ in variants}
@@ -73,7 +74,7 @@ def main():
     for name, _ in variants:
         t = sorted(times[name])
         med, mn = t[len(t) // 2], t[0]
-        print(f"  {name:12s} median {med * 1e3:8.1f} us  min {mn * 1e3:8.1f} us  {flops / (med * 1e-3) / 1e12:6.1f} TFLOP/s "
+        print(f"  {name:16s} median {med * 1e3:8.1f} us  min {mn * 1e3:8.1f} us  {flops / (med * 1e-3) / 1e12:6.1f} TFLOP/s "
               f"({flops / (med * 1e-3) / 1e12 / 157.3:.3f} of fp32 MFMA peak)  id agreement {agree[name]:.4f}")
     idx.close()
 
