@@ -13,11 +13,14 @@
  * "_device" variants take DEVICE pointers and a hipStream_t passed as void*
  * (0 = the null stream); they enqueue work and return without synchronising,
  * and are graph-capturable once amdr_*_reserve() has sized the workspace.
- * A handle owns ONE workspace: "_device" calls on the same handle must be
- * ordered with respect to each other (same stream, or events between streams);
- * the host-pointer variants are always safe to call concurrently.
- * Plain variants take HOST pointers, run on the handle's private stream and
- * return after the results are in the host buffers.
+ * A handle owns TWO workspaces: one for the "_device" calls, one for the plain
+ * (host-pointer) calls.  "_device" calls on the same handle must be ordered with
+ * respect to each other by the caller (same stream, or events between streams) —
+ * the library only enqueues and cannot know when the caller's stream gets there.
+ * Plain variants take HOST pointers, run on the handle's private stream inside
+ * the handle's mutex and return after the results are in the host buffers: they
+ * are safe to call from any number of threads, also while "_device" work of the
+ * same handle is still in flight on another stream (different workspace).
  */
 #ifndef AMDRETRIEVAL_H
 #define AMDRETRIEVAL_H
@@ -77,6 +80,10 @@ int amdr_dense_score_rows(amdr_dense_t* h, const float* Q_host, int32_t nq, cons
 /* copy rows [row0, row0+nrows) back to the host (used by parity tests to run
  * the oracle on exactly the matrix that is resident in HBM) */
 int amdr_dense_read_rows(const amdr_dense_t* h, int64_t row0, int64_t nrows, float* out_host);
+/* Which kernels a search of nq queries at depth k would launch on this index, and how the work
+ * is cut (e.g. "dense_panel_scores_kernel nb=6 parts=7 blocks=2044 + scores_slab_topk_kernel"):
+ * written NUL-terminated into buf.  No device work.  bench.py names its roofline kernel with it. */
+int amdr_dense_plan_info(const amdr_dense_t* h, int32_t nq, int32_t k, char* buf, int32_t buf_len);
 /* HIP-event bracket around the scan kernel alone (not the merge), recorded on
  * the stream each search is launched on; used by bench.py for the roofline.
  * begin() arms up to max_launches event pairs, end() returns the summed scan

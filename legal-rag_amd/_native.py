@@ -30,7 +30,7 @@ EXPORTS = (
     "amdr_last_error", "amdr_version", "amdr_device_count", "amdr_device_name",
     "amdr_dense_create", "amdr_dense_create_from_device", "amdr_dense_add", "amdr_dense_ntotal", "amdr_dense_dim",
     "amdr_dense_reserve", "amdr_dense_search", "amdr_dense_search_device", "amdr_dense_read_rows", "amdr_dense_score_rows",
-    "amdr_dense_profile_begin", "amdr_dense_profile_end", "amdr_dense_destroy",
+    "amdr_dense_plan_info", "amdr_dense_profile_begin", "amdr_dense_profile_end", "amdr_dense_destroy",
     "amdr_bm25_create", "amdr_bm25_ndocs", "amdr_bm25_reserve", "amdr_bm25_search", "amdr_bm25_search_device",
     "amdr_bm25_scores", "amdr_bm25_destroy",
     "amdr_maxsim_create", "amdr_maxsim_ndocs", "amdr_maxsim_reserve", "amdr_maxsim_search",
@@ -38,6 +38,29 @@ EXPORTS = (
     "amdr_fuse", "amdr_fuse_device", "amdr_rerank_blend", "amdr_rerank_blend_device",
     "amdr_merge_topk_f32_device", "amdr_merge_topk_f64_device",
 )
+
+
+# argument kinds of every export, in header order: P = pointer (host or device, or an opaque handle /
+# handle out-parameter / hipStream_t passed as void*), i = int32_t, l = int64_t, d = double.
+# tests/test_abi.py parses include/amdretrieval.h and checks this table against the prototypes, so a
+# wrapper can no longer pass a Python int where the ABI wants 64 bits (or the reverse) unnoticed.
+SIGNATURES = {
+    "amdr_last_error": "", "amdr_version": "", "amdr_device_count": "P", "amdr_device_name": "iPi",
+    "amdr_dense_create": "PliiP", "amdr_dense_create_from_device": "PliiP", "amdr_dense_add": "PPl",
+    "amdr_dense_ntotal": "PP", "amdr_dense_dim": "PP", "amdr_dense_reserve": "Pii", "amdr_dense_search": "PPiiPP",
+    "amdr_dense_search_device": "PPiiPPP", "amdr_dense_read_rows": "PllP", "amdr_dense_score_rows": "PPiPiP",
+    "amdr_dense_plan_info": "PiiPi", "amdr_dense_profile_begin": "Pi", "amdr_dense_profile_end": "PPP", "amdr_dense_destroy": "P",
+    "amdr_bm25_create": "PPPPPlldddiP", "amdr_bm25_ndocs": "PP", "amdr_bm25_reserve": "Piil",
+    "amdr_bm25_search": "PPPiiPP", "amdr_bm25_search_device": "PPPiiPPP", "amdr_bm25_scores": "PPPiP",
+    "amdr_bm25_destroy": "P",
+    "amdr_maxsim_create": "PPliiP", "amdr_maxsim_ndocs": "PP", "amdr_maxsim_reserve": "Pii",
+    "amdr_maxsim_search": "PPiiiPP", "amdr_maxsim_search_device": "PPiiiPPP", "amdr_maxsim_scores": "PPiiP",
+    "amdr_maxsim_destroy": "P",
+    "amdr_fuse": "Pi" + "PPi" * 3 + "PPPP", "amdr_fuse_device": "Pi" + "PPiP" * 3 + "PPPP" + "iP",
+    "amdr_rerank_blend": "iiPPPPPidP", "amdr_rerank_blend_device": "iiPPPPPidPiP",
+    "amdr_merge_topk_f32_device": "PPiiiiPPiP", "amdr_merge_topk_f64_device": "PPiiiiPPiP",
+}
+_KIND = {"P": C.c_void_p, "i": C.c_int32, "l": C.c_int64, "d": C.c_double}
 
 
 class NativeError(RuntimeError):
@@ -84,6 +107,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # raises AttributeError if a declared symbol is missing
         if name != "amdr_last_error":
             fn.restype = C.c_int
+        fn.argtypes = [_KIND[k] for k in SIGNATURES[name]]
     _lib = lib
     return lib
 
@@ -196,6 +220,13 @@ class DenseIndex:
         _check(load().amdr_dense_read_rows(self._h, C.c_int64(row0), C.c_int64(nrows), _p(out, C.c_float)),
                "amdr_dense_read_rows")
         return out
+
+    def plan_info(self, nq: int, k: int) -> str:
+        """Kernels a search of nq queries at depth k launches on this index, and the cut of the work."""
+        buf = C.create_string_buffer(512)
+        _check(load().amdr_dense_plan_info(self._h, C.c_int32(nq), C.c_int32(k), buf, C.c_int32(512)),
+               "amdr_dense_plan_info")
+        return buf.value.decode()
 
     def profile_begin(self, max_launches: int) -> None:
         _check(load().amdr_dense_profile_begin(self._h, C.c_int32(max_launches)), "amdr_dense_profile_begin")

@@ -334,7 +334,7 @@ struct amdr_bm25 {
   double* idf = nullptr;
   hipStream_t stream = nullptr;
   std::mutex mu;
-  DevBuf part, qterms, qptr, sbuf, ibuf, full;
+  DevBuf part[2], qterms, qptr, sbuf, ibuf, full;  // part[0]: "_device" calls, part[1]: host-pointer calls (see dense.hip)
 };
 
 namespace {
@@ -372,15 +372,15 @@ void bm_plan(int64_t n_docs, int nq, int k, BmPlan* p) {
   p->part_bytes = (size_t)p->nslabs * nq * k * sizeof(C64);
 }
 
-int bm_run(amdr_bm25* h, const int* q_terms_dev, const long long* q_ptr_dev, int nq, int k, double* scores_dev,
+int bm_run(amdr_bm25* h, int ws, const int* q_terms_dev, const long long* q_ptr_dev, int nq, int k, double* scores_dev,
            int64_t* ids_dev, double* full_dev, hipStream_t st) {
   BmPlan p;
   bm_plan(h->n_docs, nq, k, &p);
   C64* part = nullptr;
   if (scores_dev) {
-    int rc = h->part.ensure(p.part_bytes);
+    int rc = h->part[ws].ensure(p.part_bytes);
     if (rc) return rc;
-    part = h->part.as<C64>();
+    part = h->part[ws].as<C64>();
   }
   const bool direct = scores_dev && p.nslabs == 1;  // single slab: the block's list is the answer
   double* fs = direct ? scores_dev : nullptr;
@@ -485,7 +485,7 @@ int amdr_bm25_reserve(amdr_bm25_t* h, int32_t nq_max, int32_t k_max, int64_t tot
   AMDR_HIP(hipSetDevice(h->device));
   BmPlan p;
   bm_plan(h->n_docs, nq_max, k_max, &p);
-  int rc = h->part.ensure(p.part_bytes);
+  int rc = h->part[0].ensure(p.part_bytes);
   if (!rc) rc = h->qterms.ensure((size_t)(total_terms_max + 1) * sizeof(int));
   if (!rc) rc = h->qptr.ensure((size_t)(nq_max + 1) * sizeof(long long));
   if (!rc) rc = h->sbuf.ensure((size_t)nq_max * k_max * sizeof(double));
@@ -510,7 +510,7 @@ int amdr_bm25_search_device(amdr_bm25_t* h, const int32_t* q_terms_dev, const in
   if (nq == 0) return AMDR_OK;
   std::lock_guard<std::mutex> g(h->mu);
   AMDR_HIP(hipSetDevice(h->device));
-  return bm_run(h, q_terms_dev, (const long long*)q_ptr_dev, nq, k, scores_dev, ids_dev, nullptr, (hipStream_t)stream);
+  return bm_run(h, 0, q_terms_dev, (const long long*)q_ptr_dev, nq, k, scores_dev, ids_dev, nullptr, (hipStream_t)stream);
 }
 
 static int bm_stage_queries(amdr_bm25* h, const int32_t* q_terms, const int64_t* q_ptr, int nq) {
@@ -537,7 +537,7 @@ int amdr_bm25_search(amdr_bm25_t* h, const int32_t* q_terms, const int64_t* q_pt
   if ((rc = bm_stage_queries(h, q_terms, q_ptr, nq))) return rc;
   if ((rc = h->sbuf.ensure((size_t)nq * k * sizeof(double)))) return rc;
   if ((rc = h->ibuf.ensure((size_t)nq * k * sizeof(int64_t)))) return rc;
-  rc = bm_run(h, h->qterms.as<int>(), h->qptr.as<long long>(), nq, k, h->sbuf.as<double>(), h->ibuf.as<int64_t>(),
+  rc = bm_run(h, 1, h->qterms.as<int>(), h->qptr.as<long long>(), nq, k, h->sbuf.as<double>(), h->ibuf.as<int64_t>(),
               nullptr, h->stream);
   if (rc) return rc;
   AMDR_HIP(hipMemcpyAsync(scores_host, h->sbuf.p, (size_t)nq * k * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -555,7 +555,7 @@ int amdr_bm25_scores(amdr_bm25_t* h, const int32_t* q_terms, const int64_t* q_pt
   AMDR_HIP(hipSetDevice(h->device));
   if ((rc = bm_stage_queries(h, q_terms, q_ptr, nq))) return rc;
   if ((rc = h->full.ensure((size_t)nq * h->n_docs * sizeof(double)))) return rc;
-  rc = bm_run(h, h->qterms.as<int>(), h->qptr.as<long long>(), nq, 1, nullptr, nullptr, h->full.as<double>(),
+  rc = bm_run(h, 1, h->qterms.as<int>(), h->qptr.as<long long>(), nq, 1, nullptr, nullptr, h->full.as<double>(),
               h->stream);
   if (rc) return rc;
   AMDR_HIP(hipMemcpyAsync(scores_host, h->full.p, (size_t)nq * h->n_docs * sizeof(double), hipMemcpyDeviceToHost,
@@ -575,7 +575,8 @@ int amdr_bm25_destroy(amdr_bm25_t* h) {
   if (h->post_doc) (void)hipFree(h->post_doc);
   if (h->post_w) (void)hipFree(h->post_w);
   if (h->idf) (void)hipFree(h->idf);
-  h->part.release();
+  h->part[0].release();
+  h->part[1].release();
   h->qterms.release();
   h->qptr.release();
   h->sbuf.release();

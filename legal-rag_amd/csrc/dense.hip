@@ -291,7 +291,12 @@ struct amdr_dense {
   bool owns = true;
   hipStream_t stream = nullptr;
   std::mutex mu;
-  DevBuf part, qbuf, sbuf, ibuf, smat;
+  // Two workspaces: [0] for the "_device" entry points (kernels enqueued on the CALLER's stream,
+  // the call returns before they run), [1] for the host-pointer entry points (own stream,
+  // synchronised before the mutex is released).  A service thread in amdr_dense_search can
+  // therefore never scribble over the score matrix of a search_batch still in flight on another
+  // stream.  "_device" calls on ONE handle from SEVERAL streams remain the caller's to order.
+  DevBuf part[2], smat[2], qbuf, sbuf, ibuf;
   // optional HIP-event ring bracketing the scan kernel alone (bench.py roofline)
   std::vector<hipEvent_t> prof_ev;
   int prof_used = 0;
@@ -380,13 +385,15 @@ int batched_chunk(const amdr_dense* h, int nq) {
 
 // Two-pass form: scores S[q][row] (fp32-MFMA tiles for batches, one wave per (query, row) for the
 // 1-4 query call on a short corpus), then slab top-k (+ merge when there are several slabs).
-int run_search_batched(amdr_dense* h, const float* Q_dev, int nq, int k, float* scores_dev, int64_t* ids_dev,
+int run_search_batched(amdr_dense* h, int ws, const float* Q_dev, int nq, int k, float* scores_dev, int64_t* ids_dev,
                        hipStream_t st, bool row_waves = false) {
+  DevBuf& smat = h->smat[ws];
+  DevBuf& partb = h->part[ws];
   const int chunk = batched_chunk(h, nq);
   DenseMfmaPlan p;
   dense_mfma_plan((long)h->n, h->d, chunk, k, &p);
-  int rc = h->smat.ensure(p.s_bytes);
-  if (!rc) rc = h->part.ensure(p.part_bytes);
+  int rc = smat.ensure(p.s_bytes);
+  if (!rc) rc = partb.ensure(p.part_bytes);
   if (rc) return rc;
   for (int q0 = 0; q0 < nq; q0 += chunk) {
     const int m = nq - q0 < chunk ? nq - q0 : chunk;
@@ -395,16 +402,16 @@ int run_search_batched(amdr_dense* h, const float* Q_dev, int nq, int k, float* 
     if (prof) AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
     if (row_waves) {
       hipLaunchKernelGGL(dense_all_scores_kernel, dim3(ceil_div((long)m * h->n, kWaves)), dim3(256), 0, st, h->X,
-                         (long)h->n, h->d, Q_dev + (size_t)q0 * h->d, m, p.ld, h->smat.as<float>());
+                         (long)h->n, h->d, Q_dev + (size_t)q0 * h->d, m, p.ld, smat.as<float>());
       AMDR_HIP(hipGetLastError());
     } else if (dense_panel_supported((long)h->n, h->d, m)) {
       DensePanelPlan pp;
       dense_panel_plan((long)h->n, h->d, m, &pp);
       rc = dense_panel_launch_scores(pp, h->X, (long)h->n, h->d, Q_dev + (size_t)q0 * h->d, m, p.ld,
-                                     h->smat.as<float>(), st);
+                                     smat.as<float>(), st);
       if (rc) return rc;
     } else {
-      rc = dense_mfma_launch_scores(p, h->X, (long)h->n, h->d, Q_dev + (size_t)q0 * h->d, m, h->smat.as<float>(), st);
+      rc = dense_mfma_launch_scores(p, h->X, (long)h->n, h->d, Q_dev + (size_t)q0 * h->d, m, smat.as<float>(), st);
       if (rc) return rc;
     }
     if (prof) {
@@ -412,13 +419,13 @@ int run_search_batched(amdr_dense* h, const float* Q_dev, int nq, int k, float* 
       h->prof_used += 2;
     }
     const bool direct = p.slabs == 1;  // one slab: its list is the answer, no merge launch
-    rc = dense_mfma_launch_topk(p, h->smat.as<float>(), (long)h->n, m, k, h->part.p,
+    rc = dense_mfma_launch_topk(p, smat.as<float>(), (long)h->n, m, k, partb.p,
                                 direct ? scores_dev + (size_t)q0 * k : nullptr,
                                 direct ? ids_dev + (size_t)q0 * k : nullptr, st);
     if (rc) return rc;
     if (!direct) {
       size_t lds = (size_t)kWaves * p.cap * sizeof(C32) + kWaves * sizeof(int);
-      hipLaunchKernelGGL(dense_merge_kernel, dim3(m), dim3(256), lds, st, h->part.as<C32>(), p.slabs, m, k, p.cap,
+      hipLaunchKernelGGL(dense_merge_kernel, dim3(m), dim3(256), lds, st, partb.as<C32>(), p.slabs, m, k, p.cap,
                          scores_dev + (size_t)q0 * k, (long long*)ids_dev + (size_t)q0 * k);
       AMDR_HIP(hipGetLastError());
     }
@@ -426,16 +433,16 @@ int run_search_batched(amdr_dense* h, const float* Q_dev, int nq, int k, float* 
   return AMDR_OK;
 }
 
-int run_search(amdr_dense* h, const float* Q_dev, int nq, int k, float* scores_dev, int64_t* ids_dev,
+int run_search(amdr_dense* h, int ws, const float* Q_dev, int nq, int k, float* scores_dev, int64_t* ids_dev,
                hipStream_t st) {
   if (nq >= kBatchedMin && h->n > 0 && dense_mfma_supported(h->d))
-    return run_search_batched(h, Q_dev, nq, k, scores_dev, ids_dev, st);
-  if (h->n > 0 && h->n <= kRowWavesMax) return run_search_batched(h, Q_dev, nq, k, scores_dev, ids_dev, st, true);
+    return run_search_batched(h, ws, Q_dev, nq, k, scores_dev, ids_dev, st);
+  if (h->n > 0 && h->n <= kRowWavesMax) return run_search_batched(h, ws, Q_dev, nq, k, scores_dev, ids_dev, st, true);
   ScanPlan p;
   make_plan(h->n, h->d, nq, k, &p);
-  int rc = h->part.ensure(p.part_bytes);
+  int rc = h->part[ws].ensure(p.part_bytes);
   if (rc) return rc;
-  C32* part = h->part.as<C32>();
+  C32* part = h->part[ws].as<C32>();
   const bool prof = h->prof_on && (size_t)(h->prof_used + 2) <= h->prof_ev.size() && h->n > 0;
   if (prof) AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
   const bool direct = h->n > 0 && p.grid_x == 1;
@@ -568,19 +575,19 @@ int amdr_dense_reserve(amdr_dense_t* h, int32_t nq_max, int32_t k_max) {
   AMDR_HIP(hipSetDevice(h->device));
   ScanPlan p;
   make_plan(h->n, h->d, nq_max, k_max, &p);
-  int rc = h->part.ensure(p.part_bytes);
+  int rc = h->part[0].ensure(p.part_bytes);
   if (rc) return rc;
   if (nq_max >= kBatchedMin && h->n > 0 && dense_mfma_supported(h->d)) {
     DenseMfmaPlan mp;
     dense_mfma_plan((long)h->n, h->d, batched_chunk(h, nq_max), k_max, &mp);
-    if ((rc = h->smat.ensure(mp.s_bytes))) return rc;
-    if ((rc = h->part.ensure(mp.part_bytes))) return rc;
+    if ((rc = h->smat[0].ensure(mp.s_bytes))) return rc;
+    if ((rc = h->part[0].ensure(mp.part_bytes))) return rc;
   }
   if (h->n > 0 && h->n <= kRowWavesMax) {  // the 1-4 query call on a short corpus also goes through S
     DenseMfmaPlan mp;
     dense_mfma_plan((long)h->n, h->d, nq_max < kBatchedMin ? nq_max : kBatchedMin - 1, k_max, &mp);
-    if ((rc = h->smat.ensure(mp.s_bytes))) return rc;
-    if ((rc = h->part.ensure(mp.part_bytes))) return rc;
+    if ((rc = h->smat[0].ensure(mp.s_bytes))) return rc;
+    if ((rc = h->part[0].ensure(mp.part_bytes))) return rc;
   }
   if ((rc = h->qbuf.ensure((size_t)nq_max * h->d * sizeof(float)))) return rc;
   if ((rc = h->sbuf.ensure((size_t)nq_max * k_max * sizeof(float)))) return rc;
@@ -594,7 +601,7 @@ int amdr_dense_search_device(amdr_dense_t* h, const float* Q_dev, int32_t nq, in
   if (nq == 0) return AMDR_OK;
   std::lock_guard<std::mutex> g(h->mu);
   AMDR_HIP(hipSetDevice(h->device));
-  return run_search(h, Q_dev, nq, k, scores_dev, ids_dev, (hipStream_t)stream);
+  return run_search(h, 0, Q_dev, nq, k, scores_dev, ids_dev, (hipStream_t)stream);
 }
 
 int amdr_dense_search(amdr_dense_t* h, const float* Q_host, int32_t nq, int32_t k, float* scores_host,
@@ -608,7 +615,7 @@ int amdr_dense_search(amdr_dense_t* h, const float* Q_host, int32_t nq, int32_t 
   if ((rc = h->sbuf.ensure((size_t)nq * k * sizeof(float)))) return rc;
   if ((rc = h->ibuf.ensure((size_t)nq * k * sizeof(int64_t)))) return rc;
   AMDR_HIP(hipMemcpyAsync(h->qbuf.p, Q_host, (size_t)nq * h->d * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  rc = run_search(h, h->qbuf.as<float>(), nq, k, h->sbuf.as<float>(), h->ibuf.as<int64_t>(), h->stream);
+  rc = run_search(h, 1, h->qbuf.as<float>(), nq, k, h->sbuf.as<float>(), h->ibuf.as<int64_t>(), h->stream);
   if (rc) return rc;
   AMDR_HIP(hipMemcpyAsync(scores_host, h->sbuf.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   AMDR_HIP(hipMemcpyAsync(ids_host, h->ibuf.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
@@ -647,6 +654,39 @@ int amdr_dense_read_rows(const amdr_dense_t* h, int64_t row0, int64_t nrows, flo
   if (nrows)
     AMDR_HIP(hipMemcpy(out_host, h->X + (size_t)row0 * h->d, (size_t)nrows * h->d * sizeof(float),
                        hipMemcpyDeviceToHost));
+  return AMDR_OK;
+}
+
+int amdr_dense_plan_info(const amdr_dense_t* h, int32_t nq, int32_t k, char* buf, int32_t buf_len) {
+  AMDR_REQUIRE(h && buf && buf_len > 0, "dense_plan_info: null");
+  AMDR_REQUIRE(nq >= 1 && k >= 1 && k <= AMDR_MAX_K, "dense_plan_info: bad sizes");
+  if (h->n <= 0) {
+    snprintf(buf, buf_len, "empty index");
+    return AMDR_OK;
+  }
+  const bool batched = nq >= kBatchedMin && dense_mfma_supported(h->d);
+  if (batched || h->n <= kRowWavesMax) {
+    const int m = batched_chunk(h, nq);
+    DenseMfmaPlan p;
+    dense_mfma_plan((long)h->n, h->d, m, k, &p);
+    const char* tail = p.slabs == 1 ? "scores_slab_topk_kernel" : "scores_slab_topk_kernel + dense_merge_kernel";
+    if (!batched) {
+      snprintf(buf, buf_len, "dense_all_scores_kernel (one wave per query x row) + %s", tail);
+    } else if (dense_panel_supported((long)h->n, h->d, m)) {
+      DensePanelPlan pp;
+      dense_panel_plan((long)h->n, h->d, m, &pp);
+      snprintf(buf, buf_len, "dense_panel_scores_kernel nb=%d parts=%d blocks=%d queries_per_launch=%d + %s", pp.nb,
+               pp.parts, pp.m_tiles * pp.parts, m, tail);
+    } else {
+      snprintf(buf, buf_len, "dense_mfma_scores_kernel %s grid=%dx%d queries_per_launch=%d + %s",
+               p.transposed ? "chunk-tiles-in-LDS" : "query-tiles-in-LDS", p.grid_x, p.grid_y, m, tail);
+    }
+    return AMDR_OK;
+  }
+  ScanPlan p;
+  make_plan(h->n, h->d, nq, k, &p);
+  snprintf(buf, buf_len, "dense_scan_topk_kernel<NQ=%d> grid=%dx%d%s", p.nq_per_block, p.grid_x, p.grid_y,
+           p.grid_x == 1 ? "" : " + dense_merge_kernel");
   return AMDR_OK;
 }
 
@@ -691,8 +731,10 @@ int amdr_dense_destroy(amdr_dense_t* h) {
     (void)hipStreamDestroy(h->stream);
   }
   if (h->owns && h->X) (void)hipFree(h->X);
-  h->part.release();
-  h->smat.release();
+  for (int w = 0; w < 2; ++w) {
+    h->part[w].release();
+    h->smat[w].release();
+  }
   h->qbuf.release();
   h->sbuf.release();
   h->ibuf.release();

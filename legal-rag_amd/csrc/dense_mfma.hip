@@ -438,15 +438,14 @@ void dense_mfma_plan(long n, int d, int nq, int k, DenseMfmaPlan* p) {
 }
 
 template <int D8, int WAVES, bool TR>
-static void launch_scores(const DenseMfmaPlan& p, const float* X, long n, const float* Q, int nq, float* S,
-                          hipStream_t st) {
-  static bool attr_done = false;  // 128-160 KiB of dynamic LDS needs the opt-in once per kernel
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)dense_mfma_scores_kernel<D8, WAVES, TR>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                              D8 * 8 * 32 * (int)sizeof(float) + WAVES * kStageBufs * kStageBytes);
-    attr_done = true;
-  }
+static int launch_scores(const DenseMfmaPlan& p, const float* X, long n, const float* Q, int nq, float* S,
+                         hipStream_t st) {
+  // 128-160 KiB of dynamic LDS needs the opt-in.  The attribute belongs to the (function, device)
+  // pair, the C ABI takes a device ordinal, and setting it is cheap: set on every launch for the
+  // current device rather than remembering "done" per process.
+  AMDR_HIP(hipFuncSetAttribute((const void*)dense_mfma_scores_kernel<D8, WAVES, TR>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                               D8 * 8 * 32 * (int)sizeof(float) + WAVES * kStageBufs * kStageBytes));
   // TR: the query matrix is the streamed operand, the chunk matrix the tiled one
   if (TR)
     hipLaunchKernelGGL((dense_mfma_scores_kernel<D8, WAVES, true>), dim3(p.grid_x * p.grid_y), dim3(WAVES * 64),
@@ -454,17 +453,17 @@ static void launch_scores(const DenseMfmaPlan& p, const float* X, long n, const 
   else
     hipLaunchKernelGGL((dense_mfma_scores_kernel<D8, WAVES, false>), dim3(p.grid_x * p.grid_y), dim3(WAVES * 64),
                        p.lds_scores, st, X, n, Q, nq, p.rows_per_block, p.grid_x, p.grid_y, p.ld, S);
+  return AMDR_OK;
 }
 
 int dense_mfma_launch_scores(const DenseMfmaPlan& p, const float* X, long n, int d, const float* Q, int nq, float* S,
                              hipStream_t st) {
+  int rc = AMDR_OK;
   switch (d) {
-#define AMDR_CASE(D)                                                          \
-  case D:                                                                     \
-    if (p.transposed)                                                         \
-      launch_scores<D / 8, scores_waves(D), true>(p, X, n, Q, nq, S, st);     \
-    else                                                                      \
-      launch_scores<D / 8, scores_waves(D), false>(p, X, n, Q, nq, S, st);    \
+#define AMDR_CASE(D)                                                               \
+  case D:                                                                          \
+    rc = p.transposed ? launch_scores<D / 8, scores_waves(D), true>(p, X, n, Q, nq, S, st)   \
+                      : launch_scores<D / 8, scores_waves(D), false>(p, X, n, Q, nq, S, st); \
     break;
     AMDR_CASE(64) AMDR_CASE(128) AMDR_CASE(192) AMDR_CASE(256) AMDR_CASE(320) AMDR_CASE(384)
     AMDR_CASE(448) AMDR_CASE(512) AMDR_CASE(576) AMDR_CASE(640) AMDR_CASE(704) AMDR_CASE(768)
@@ -472,6 +471,7 @@ int dense_mfma_launch_scores(const DenseMfmaPlan& p, const float* X, long n, int
 #undef AMDR_CASE
     default: return fail(AMDR_EINVAL, "dense (batched): unsupported dim %d", d);
   }
+  if (rc) return rc;
   AMDR_HIP(hipGetLastError());
   return AMDR_OK;
 }

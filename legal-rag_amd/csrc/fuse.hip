@@ -661,15 +661,17 @@ int amdr_fuse(const amdr_fuse_params_t* p, int32_t nq, const int64_t* dense_ids,
   if ((rc = arena().begin(dev, total))) return rc;
   char* d = arena().base;
   hipStream_t st = nullptr;
-  AMDR_HIP(hipMemcpyAsync(d, host_block().data(), in_bytes, hipMemcpyHostToDevice, st));
+  // the pageable block is sized for the outputs BEFORE the asynchronous copy reads it: growing
+  // it afterwards would free the source of a copy that is nominally still in flight
+  std::vector<char>& hb = host_block();
+  if (hb.size() < total) hb.resize(total);
+  AMDR_HIP(hipMemcpyAsync(d, hb.data(), in_bytes, hipMemcpyHostToDevice, st));
   ChanIn c0{(const long long*)(d + o_di), d + o_ds, nullptr, kd, 1};
   ChanIn c1{(const long long*)(d + o_bi), d + o_bs, nullptr, kb, 1};
   ChanIn c2{(const long long*)(d + o_ci), d + o_cs, nullptr, kc, 1};
   launch_fuse(*p, c0, c1, c2, nq, (int)mo, (long long*)(d + o_oi), (double*)(d + o_ov), (int*)(d + o_om),
               (int*)(d + o_oc), st);
   AMDR_HIP(hipGetLastError());
-  std::vector<char>& hb = host_block();
-  if (hb.size() < total) hb.resize(total);
   AMDR_HIP(hipMemcpyAsync(hb.data() + o_oi, d + o_oi, total - o_oi, hipMemcpyDeviceToHost, st));
   AMDR_HIP(hipStreamSynchronize(st));
   memcpy(out_ids, hb.data() + o_oi, q * mo * 8);
@@ -697,12 +699,14 @@ int amdr_rerank_blend(int32_t nq, int32_t max_out, const int32_t* count, int64_t
   if ((rc = arena().begin(dev, total))) return rc;
   char* d = arena().base;
   hipStream_t st = nullptr;
-  AMDR_HIP(hipMemcpyAsync(d, host_block().data(), in_bytes, hipMemcpyHostToDevice, st));
+  // the pageable block is sized for the outputs BEFORE the asynchronous copy reads it: growing
+  // it afterwards would free the source of a copy that is nominally still in flight
+  std::vector<char>& hb = host_block();
+  if (hb.size() < total) hb.resize(total);
+  AMDR_HIP(hipMemcpyAsync(d, hb.data(), in_bytes, hipMemcpyHostToDevice, st));
   rc = amdr_rerank_blend_device(nq, max_out, (const int32_t*)(d + o_c), (int64_t*)(d + o_i), (double*)(d + o_v),
                                 (int32_t*)(d + o_m), (const double*)(d + o_r), top_n, beta, (double*)(d + o_o), dev, st);
   if (rc) return rc;
-  std::vector<char>& hb = host_block();
-  if (hb.size() < total) hb.resize(total);
   AMDR_HIP(hipMemcpyAsync(hb.data() + o_i, d + o_i, total - o_i, hipMemcpyDeviceToHost, st));
   AMDR_HIP(hipStreamSynchronize(st));
   memcpy(ids, hb.data() + o_i, q * mo * 8);

@@ -284,7 +284,7 @@ struct amdr_maxsim {
   long long* doc_ptr = nullptr;
   hipStream_t stream = nullptr;
   std::mutex mu;
-  DevBuf full, qbuf, sbuf, ibuf;
+  DevBuf full[2], qbuf, sbuf, ibuf;  // full[0]: "_device" calls, full[1]: host-pointer calls (see dense.hip)
 };
 
 namespace {
@@ -367,7 +367,7 @@ int amdr_maxsim_reserve(amdr_maxsim_t* h, int32_t nq_max, int32_t k_max) {
   AMDR_REQUIRE(nq_max >= 1 && k_max >= 1 && k_max <= AMDR_MAX_K, "maxsim_reserve: bad sizes");
   std::lock_guard<std::mutex> g(h->mu);
   AMDR_HIP(hipSetDevice(h->device));
-  int rc = h->full.ensure((size_t)nq_max * h->n_docs * sizeof(float));
+  int rc = h->full[0].ensure((size_t)nq_max * h->n_docs * sizeof(float));
   if (!rc) rc = h->qbuf.ensure((size_t)nq_max * AMDR_MAXSIM_QLEN * kDim * sizeof(float));
   if (!rc) rc = h->sbuf.ensure((size_t)nq_max * k_max * sizeof(float));
   if (!rc) rc = h->ibuf.ensure((size_t)nq_max * k_max * sizeof(int64_t));
@@ -382,8 +382,8 @@ int amdr_maxsim_search_device(amdr_maxsim_t* h, const float* Q_dev, int32_t nq, 
   if (nq == 0) return AMDR_OK;
   std::lock_guard<std::mutex> g(h->mu);
   AMDR_HIP(hipSetDevice(h->device));
-  if ((rc = h->full.ensure((size_t)nq * h->n_docs * sizeof(float)))) return rc;
-  return ms_run(h, Q_dev, nq, q_len, k, h->full.as<float>(), scores_dev, ids_dev, (hipStream_t)stream);
+  if ((rc = h->full[0].ensure((size_t)nq * h->n_docs * sizeof(float)))) return rc;
+  return ms_run(h, Q_dev, nq, q_len, k, h->full[0].as<float>(), scores_dev, ids_dev, (hipStream_t)stream);
 }
 
 int amdr_maxsim_search(amdr_maxsim_t* h, const float* Q_host, int32_t nq, int32_t q_len, int32_t k,
@@ -396,11 +396,11 @@ int amdr_maxsim_search(amdr_maxsim_t* h, const float* Q_host, int32_t nq, int32_
   AMDR_HIP(hipSetDevice(h->device));
   size_t qbytes = (size_t)nq * q_len * kDim * sizeof(float);
   if ((rc = h->qbuf.ensure(qbytes))) return rc;
-  if ((rc = h->full.ensure((size_t)nq * h->n_docs * sizeof(float)))) return rc;
+  if ((rc = h->full[1].ensure((size_t)nq * h->n_docs * sizeof(float)))) return rc;
   if ((rc = h->sbuf.ensure((size_t)nq * k * sizeof(float)))) return rc;
   if ((rc = h->ibuf.ensure((size_t)nq * k * sizeof(int64_t)))) return rc;
   AMDR_HIP(hipMemcpyAsync(h->qbuf.p, Q_host, qbytes, hipMemcpyHostToDevice, h->stream));
-  rc = ms_run(h, h->qbuf.as<float>(), nq, q_len, k, h->full.as<float>(), h->sbuf.as<float>(), h->ibuf.as<int64_t>(),
+  rc = ms_run(h, h->qbuf.as<float>(), nq, q_len, k, h->full[1].as<float>(), h->sbuf.as<float>(), h->ibuf.as<int64_t>(),
               h->stream);
   if (rc) return rc;
   AMDR_HIP(hipMemcpyAsync(scores_host, h->sbuf.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -418,11 +418,11 @@ int amdr_maxsim_scores(amdr_maxsim_t* h, const float* Q_host, int32_t nq, int32_
   AMDR_HIP(hipSetDevice(h->device));
   size_t qbytes = (size_t)nq * q_len * kDim * sizeof(float);
   if ((rc = h->qbuf.ensure(qbytes))) return rc;
-  if ((rc = h->full.ensure((size_t)nq * h->n_docs * sizeof(float)))) return rc;
+  if ((rc = h->full[1].ensure((size_t)nq * h->n_docs * sizeof(float)))) return rc;
   AMDR_HIP(hipMemcpyAsync(h->qbuf.p, Q_host, qbytes, hipMemcpyHostToDevice, h->stream));
-  rc = ms_run(h, h->qbuf.as<float>(), nq, q_len, 1, h->full.as<float>(), nullptr, nullptr, h->stream);
+  rc = ms_run(h, h->qbuf.as<float>(), nq, q_len, 1, h->full[1].as<float>(), nullptr, nullptr, h->stream);
   if (rc) return rc;
-  AMDR_HIP(hipMemcpyAsync(scores_host, h->full.p, (size_t)nq * h->n_docs * sizeof(float), hipMemcpyDeviceToHost,
+  AMDR_HIP(hipMemcpyAsync(scores_host, h->full[1].p, (size_t)nq * h->n_docs * sizeof(float), hipMemcpyDeviceToHost,
                           h->stream));
   AMDR_HIP(hipStreamSynchronize(h->stream));
   return AMDR_OK;
@@ -437,7 +437,8 @@ int amdr_maxsim_destroy(amdr_maxsim_t* h) {
   }
   if (h->D) (void)hipFree(h->D);
   if (h->doc_ptr) (void)hipFree(h->doc_ptr);
-  h->full.release();
+  h->full[0].release();
+  h->full[1].release();
   h->qbuf.release();
   h->sbuf.release();
   h->ibuf.release();

@@ -7,7 +7,8 @@ an LLM-driven generator (scripts/generate_synthetic_data.py) that cannot run
 offline, so `synthetic_queries` builds a seeded stand-in set from the corpus
 itself: for every section a TITLE query (the heading after "§ x-yyy.") and a
 SPAN query (a seeded 12-word window of the body); gold = that section's
-article_id.
+article_id.  Chinese articles (no word separators) get a seeded 16-character
+window of the article body instead.
 """
 from __future__ import annotations
 
@@ -58,11 +59,17 @@ def all_metrics(pred: List[str], gold: Set[str]) -> Dict[str, float]:
 _TITLE_RE = re.compile(r"^§\s*[\w\-\.]+?\.\s+(.+?)\.(?:\s|$)")
 
 
-def synthetic_queries(chunks, seed: int = 0, span_words: int = 12) -> List[Tuple[str, str, str]]:
+def synthetic_queries(chunks, seed: int = 0, span_words: int = 12, span_chars: int = 16) -> List[Tuple[str, str, str]]:
     """[(query, gold article_id, kind)] — deterministic for a given corpus + seed."""
     rng = np.random.default_rng(seed)
     out: List[Tuple[str, str, str]] = []
     for c in chunks:
+        if (getattr(c, "lang", None) or "").lower() == "zh":
+            body = c.text.split(" ", 1)[-1].strip()  # drop the "第N条" head
+            if len(body) >= span_chars + 6:
+                s = int(rng.integers(0, len(body) - span_chars))
+                out.append((body[s:s + span_chars], c.article_id, "span_zh"))
+            continue
         m = _TITLE_RE.match(c.text)
         if m and 3 <= len(m.group(1)) <= 200:
             out.append((m.group(1).strip(), c.article_id, "title"))

@@ -41,7 +41,7 @@ class BM25Retriever:
         self.chunks: List[LawChunk] = []
         self._lock = threading.Lock()
         self.index_tokenizer: Optional[str] = None  # id recorded in bm25.pkl (None: reference-built)
-        self.zh_exact = True                          # False once a query was tokenised by the stand-in
+        self._tls = threading.local()                 # per-thread: did the last query use the stand-in?
 
     def load(self) -> None:
         if not self.bm25_path.exists():
@@ -60,7 +60,6 @@ class BM25Retriever:
             self.chunks = chunks
             self.index_tokenizer = bm25.__dict__.get("_tokenizer_id")
             if self.index_tokenizer == "char":
-                self.zh_exact = False
                 logger.warning("[BM25] %s was built with the one-character stand-in tokenizer: results differ "
                                "from a jieba-built index (zh_exact=False)", self.bm25_path)
             self._loaded = True
@@ -74,14 +73,23 @@ class BM25Retriever:
             toks = text.jieba_cut_restated(query)  # same stand-in as the index, whatever is installed
         else:
             toks = text.jieba_cut(query, mode)
-        if text.contains_han(query) and (self.index_tokenizer == "char" or not text.zh_exact()):
-            self.zh_exact = False
+        self._tls.exact = not (text.contains_han(query) and (self.index_tokenizer == "char" or not text.zh_exact()))
         return toks
+
+    @property
+    def zh_exact(self) -> bool:
+        """False when this thread's last query (or the index itself) went through the
+        one-character stand-in instead of jieba."""
+        return self.index_tokenizer != "char" and getattr(self._tls, "exact", True)
 
     def search(self, query: str, top_k: int, tokens: Optional[Sequence[str]] = None) -> List[Tuple[LawChunk, float]]:
         self.load()
         assert self.bm25 is not None
-        tokens = list(tokens) if tokens is not None else self.tokenize_query(query)
+        if tokens is not None:
+            tokens = list(tokens)
+            self._tls.exact = True
+        else:
+            tokens = self.tokenize_query(query)
         k = int(top_k)
         if k <= 0:
             return []

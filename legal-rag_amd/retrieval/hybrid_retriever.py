@@ -158,13 +158,16 @@ class HybridRetriever:
     def search_bm25(self, question: str, top_k: int = 10, tokens: Optional[Sequence[str]] = None) -> List[RetrievalHit]:
         """`tokens`: the caller's own segmentation of `question` (exact path without jieba)."""
         top_k = max(1, int(top_k))
+        # (a duck-typed retriever with the reference's two-argument search() is still accepted)
+        pairs = self.bm25.search(question, top_k, tokens=tokens) if tokens is not None else self.bm25.search(question, top_k)
         hits = [RetrievalHit(chunk=c, score=float(s), rank=i, source="retriever",
                              score_breakdown={"channel": ["bm25"], "bm25_raw": float(s)})
-                for i, (c, s) in enumerate(self.bm25.search(question, top_k, tokens=tokens), start=1)]
+                for i, (c, s) in enumerate(pairs, start=1)]
         hits.sort(key=lambda h: float(h.score), reverse=True)
+        inexact = not getattr(self.bm25, "zh_exact", True)  # stand-in tokenizer ran: never unmarked (text.py)
         for i, h in enumerate(hits, start=1):
             h.rank = i
-            if not self.bm25.zh_exact:  # stand-in tokenizer ran: never unmarked (text.py)
+            if inexact:
                 h.score_breakdown["zh_exact"] = False
         return hits
 
@@ -255,6 +258,9 @@ class HybridRetriever:
         ids, vals, mask, count = _native.fuse(self._params(kn, _min_final), 1, arr(dense_hits), arr(bm25_hits),
                                               arr(colbert_hits))
         hits = self._hits_from_native(ids[0], vals[0], mask[0], ids.shape[1], kn, chunk_of)
+        if any((h.score_breakdown or {}).get("zh_exact") is False for h in bm25_hits):
+            for h in hits:  # the stand-in tokenizer's mark survives fusion (text.py)
+                h.score_breakdown["zh_exact"] = False
         if _return_native:
             return hits, (ids, vals, mask, count)
         return hits
@@ -389,7 +395,10 @@ class HybridRetriever:
         eng = HybridEngine(self.dense.store.index.native, self.bm25.bm25.gpu(dev),
                            self.colbert._searcher if self.colbert is not None else None, device=dev)
         Q = self.dense.store._embed(list(questions), is_query=True)
-        tids = [self.bm25.bm25.term_ids(self.bm25.tokenize_query(q)) for q in questions]
+        tids, exact = [], []
+        for q in questions:
+            tids.append(self.bm25.bm25.term_ids(self.bm25.tokenize_query(q)))
+            exact.append(self.bm25.zh_exact)
         qt, qp = _native.BM25Index.pack_queries(tids)
         q_tok = None
         if self.colbert is not None:
@@ -406,5 +415,8 @@ class HybridRetriever:
         out = []
         for qi in range(len(questions)):
             hits = self._hits_from_native(ids[qi], vals[qi], mask[qi], int(cnt[qi]), kn, chunks)
+            if not exact[qi]:
+                for h in hits:
+                    h.score_breakdown["zh_exact"] = False
             out.append(_dedup_keep_best(hits)[:top_k])
         return out

@@ -34,6 +34,41 @@ def test_binding_table_matches_header():
     assert sorted(_native.EXPORTS) == header_symbols()
 
 
+def header_prototypes():
+    """name -> argument kinds ('P' pointer, 'i' int32_t, 'l' int64_t, 'd' double) parsed from the header."""
+    src = (ROOT / "include" / "amdretrieval.h").read_text()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for name, args in re.findall(r"\b(amdr_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", src):
+        kinds = ""
+        for a in [x.strip() for x in args.split(",") if x.strip() and x.strip() != "void"]:
+            if "*" in a:
+                kinds += "P"
+            elif re.search(r"\bint64_t\b", a):
+                kinds += "l"
+            elif re.search(r"\bint32_t\b|\bint\b", a):
+                kinds += "i"
+            elif re.search(r"\bdouble\b", a):
+                kinds += "d"
+            else:
+                raise AssertionError(f"{name}: unrecognised parameter '{a}'")
+        out[name] = kinds
+    return out
+
+
+def test_argtypes_table_matches_header_prototypes():
+    """Every export has ctypes argtypes, and they are the header's parameter kinds (no call depends
+    on a wrapper remembering to wrap a Python int in the right width)."""
+    from legal_rag_amd import _native
+    protos = header_prototypes()
+    assert sorted(protos) == sorted(_native.EXPORTS)
+    for name, kinds in protos.items():
+        assert _native.SIGNATURES[name] == kinds, (name, _native.SIGNATURES[name], kinds)
+    lib = _native.load()
+    for name in _native.EXPORTS:
+        assert getattr(lib, name).argtypes is not None and len(getattr(lib, name).argtypes) == len(protos[name])
+
+
 def test_version_and_error_string_without_gpu():
     from legal_rag_amd import _native
     lib = _native.load()

@@ -21,6 +21,7 @@ def two_lang_index(tmp_path_factory):
     base = AppConfig.for_data_dir(str(data), "zh")
     base.retrieval.encoder_backend = "hashing"
     base.retrieval.enable_colbert = False
+    base.retrieval.zh_tokenizer = "char"  # jieba is absent here: explicit opt-in to the stand-in (text.py)
     out = {}
     for lang in ("zh", "en"):
         cfg = base.with_lang(lang)
@@ -49,11 +50,16 @@ def test_by_lang_routing_with_rerank(two_lang_index, monkeypatch):
     assert set(r._retrievers) == {"zh", "en"}
     assert all(h.source == "rerank" and "rerank_norm" in h.score_breakdown for h in zh_hits + en_hits)
     # zh BM25 channel vs the oracle on the same (fallback, per-character) tokenisation
-    toks = [text.jieba_cut(c.text) for c in chunks["zh"]]
+    toks = [text.jieba_cut(c.text, "char") for c in chunks["zh"]]
     ob = OB.BM25Okapi(toks)
     got = r._retrievers["zh"].search_bm25(zh_q, 10)
-    exp = OB.search(ob, text.jieba_cut(zh_q), 10)
+    exp = OB.search(ob, text.jieba_cut(zh_q, "char"), 10)
     assert [(h.chunk.id, h.score) for h in got] == [(chunks["zh"][i].id, s) for i, s in exp]
+    if not text.zh_exact():  # the stand-in never goes unmarked
+        assert r._retrievers["zh"].bm25.index_tokenizer == "char"
+        assert all(h.score_breakdown.get("zh_exact") is False for h in got)
+        assert all(h.score_breakdown.get("zh_exact") is False for h in zh_hits)
+        assert all("zh_exact" not in h.score_breakdown for h in en_hits)
 
 
 def test_row_sharded_engine_equals_unsharded(two_lang_index):

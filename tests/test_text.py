@@ -34,3 +34,85 @@ def test_detect_lang():
     assert text.detect_lang("What is a merchant?") == "en"
     assert text.detect_lang("认购书是否属于预约合同") == "zh"
     assert text.detect_lang("合同 contract law rules") == "en"
+
+
+# ---- Han text is never tokenised silently by a stand-in (bm25_retriever.py:73, bm25_builder.py:43) ----
+ZH = "当事人订立合同"
+
+
+def test_han_without_segmenter_raises(monkeypatch):
+    monkeypatch.setattr(text, "HAVE_JIEBA", False)
+    monkeypatch.setattr(text, "_custom_cut", None)
+    monkeypatch.delenv("LEGALRAG_ZH_TOKENIZER", raising=False)
+    with pytest.raises(text.ZhTokenizerUnavailable):
+        text.jieba_cut(ZH)
+    assert text.jieba_cut("plain ASCII, no Han") == text.jieba_cut_restated("plain ASCII, no Han")  # exact restatement
+    assert not text.zh_exact()
+    assert text.tokenizer_id() == "jieba-restated-ascii"
+
+
+def test_char_mode_is_explicit_and_logged(monkeypatch, caplog):
+    monkeypatch.setattr(text, "HAVE_JIEBA", False)
+    monkeypatch.setattr(text, "_custom_cut", None)
+    monkeypatch.setattr(text, "_warned_char", False)
+    with caplog.at_level("WARNING"):
+        assert text.jieba_cut(ZH, "char") == list(ZH)
+        text.jieba_cut(ZH, "char")
+    assert sum("one character per token" in r.getMessage() for r in caplog.records) == 1  # once
+    assert text.tokenizer_id("char") == "char"
+    monkeypatch.setenv("LEGALRAG_ZH_TOKENIZER", "char")
+    assert text.jieba_cut(ZH) == list(ZH)
+
+
+def test_wheel_or_registered_tokenizer_wins(monkeypatch):
+    class FakeJieba:
+        @staticmethod
+        def cut(s):
+            return iter(["当事人", "订立", "合同"]) if s == ZH else iter([s])
+    monkeypatch.setattr(text, "_custom_cut", None)
+    monkeypatch.setattr(text, "HAVE_JIEBA", True)
+    monkeypatch.setattr(text, "_jieba", FakeJieba, raising=False)
+    assert text.jieba_cut(ZH) == ["当事人", "订立", "合同"]
+    assert text.zh_exact() and text.tokenizer_id() == "jieba"
+    monkeypatch.setattr(text, "HAVE_JIEBA", False)
+    text.register_tokenizer(lambda s: s.split("立"), "mine")
+    try:
+        assert text.jieba_cut(ZH) == ["当事人订", "合同"]
+        assert text.zh_exact() and text.tokenizer_id() == "mine"
+    finally:
+        text.register_tokenizer(None)
+    assert not text.zh_exact()
+
+
+def _zh_chunks():
+    from legal_rag_amd.schemas import LawChunk
+    return [LawChunk(id=f"z{i}", law_name="民法典", chapter="c", section="s", article_no=str(i), article_id=f"a{i}",
+                     text=t, lang="zh", source="s.txt") for i, t in enumerate(["当事人订立合同", "合同的内容由当事人约定"])]
+
+
+def test_bm25_builder_refuses_han_without_segmenter_and_records_tokenizer(tmp_path, monkeypatch):
+    from types import SimpleNamespace
+    from legal_rag_amd import artifacts
+    from legal_rag_amd.retrieval.builders.bm25_builder import build_bm25_index
+    monkeypatch.setattr(text, "HAVE_JIEBA", False)
+    monkeypatch.setattr(text, "_custom_cut", None)
+    monkeypatch.delenv("LEGALRAG_ZH_TOKENIZER", raising=False)
+    chunks = _zh_chunks()
+    cfg = SimpleNamespace(retrieval=SimpleNamespace(bm25_index_file=str(tmp_path / "bm25.pkl")))
+    with pytest.raises(text.ZhTokenizerUnavailable):
+        build_bm25_index(cfg, chunks)
+    assert not (tmp_path / "bm25.pkl").exists()
+    # explicit opt-in: built, and the pickle says so
+    cfg.retrieval.zh_tokenizer = "char"
+    build_bm25_index(cfg, chunks)
+    bm, back = artifacts.read_bm25_pickle(tmp_path / "bm25.pkl")
+    assert bm.__dict__["_tokenizer_id"] == "char" and [c.id for c in back] == ["z0", "z1"]
+    assert set(bm.idf) == set("".join(c.text for c in chunks))
+    # pre-tokenised documents: the exact path without jieba
+    cfg.retrieval.zh_tokenizer = "jieba"
+    build_bm25_index(cfg, chunks, tokens=[["当事人", "订立", "合同"], ["合同", "的", "内容", "由", "当事人", "约定"]],
+                     tokenizer="jieba-offline")
+    bm, _ = artifacts.read_bm25_pickle(tmp_path / "bm25.pkl")
+    assert bm.__dict__["_tokenizer_id"] == "jieba-offline" and "当事人" in bm.idf and bm.doc_len == [3, 6]
+    with pytest.raises(ValueError):
+        build_bm25_index(cfg, chunks, tokens=[["x"]])
