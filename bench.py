@@ -3,30 +3,43 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ucc_hybrid|synth10m]
 
-Contract (driver): one JSON line on rank 0.  metric = queries/sec (+ Recall@10
-of the hybrid top-10) on the UCC-en corpus, BASELINE.json configs[1]
-(dense + BM25 + fusion, top-10, 1 x MI355X).  A "step" = one pass of the hot
-path (dense scan + top-k, BM25 scoring + top-k, fusion, min_final filter) over
-one batch of queries whose embeddings / term ids are already resident in HBM.
-N > 1: one process per GPU; for the UCC-en workload every rank holds a replica
-of the 1.8 MB corpus and answers its own batch ("weak", no data-path
-collective); `--shard corpus` row-shards the corpus instead and adds the RCCL
-all-gather + merge of the per-shard top-k (the layout used when the chunk
-matrix does not fit one GPU, e.g. --workload synth10m).
+Contract (driver): ONE JSON line on rank 0.  metric = queries/sec (+ Recall@10 of the hybrid
+top-10) on the UCC-en corpus, BASELINE.json configs[1] (dense + BM25 + fusion, top-10,
+1 x MI355X).  A "step" = one pass of the hot path (dense scores + top-k, BM25 scoring + top-k,
+fusion, min_final filter) over one batch of queries whose embeddings / term ids are already
+resident in HBM.  The K-step timed region (barrier + synchronize on both sides, max over ranks)
+is repeated over `--windows` windows in the same run; `value` is the MEDIAN window and every
+window is listed in `timing`.
 
-Extra objects in the same line:
-  roofline      dominant kernel (dense scan) of the timed region, HIP events
-                bracketing that kernel on its launch stream
-  cpu_baseline  the oracle (oracle/, numpy) timed on this box's host cores
-  hbm_scan      the dense channel on the synthetic 10M x 768 matrix (BASELINE.json
-                configs[4]) at 4 and 32 queries per scan — the HBM-roofline evidence
+Objects in the same line (rank 0, N = 1 unless noted):
+  roofline            dominant kernel of the timed region (dense scores), HIP events bracketing
+                      that kernel on its launch stream, all windows
+  ucc_colbert         BASELINE configs[2]: dense + BM25 + ColBERT MaxSim hybrid, own roofline
+  full_hybrid_rerank  BASELINE configs[3] on one GPU: Civil-Code-zh + UCC-en behind language
+                      routing, dense + BM25 + ColBERT -> fuse -> filter -> rerank blend with the
+                      stand-in cross-encoder scores resident in HBM, own roofline
+  api                 HybridRetriever.search() p50/p99 and search_batch() queries/s through the
+                      reference-shaped Python API (tokenisation, stand-in encoders, D2H and hit
+                      construction included)
+  hbm_scan            the dense channel on the synthetic 10M x 768 matrix (configs[4]) at 4 and
+                      32 queries per scan — the HBM-roofline evidence
+  cpu_baseline        the oracle (oracle/, numpy) timed on this box's host cores
+  scale_synth10m      N > 1 only: the row-sharded layout (HIP scan per shard -> RCCL
+                      all_gather_into_tensor -> merge_parts_kernel) on the synthetic matrix, with
+                      per-rank scan time, collective + merge time and agreement with an
+                      unsharded prefix oracle
+N > 1: one process per GPU.  The UCC-en `value` is replicas + query sharding (every rank holds
+the 1.8 MB corpus and answers its own batch: weak scaling, no data-path collective);
+`--shard corpus` row-shards the UCC corpus instead.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
+import tempfile
 import time
 from pathlib import Path
 
@@ -39,14 +52,17 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA == fp32 vector peak
 
 
-def pmc_traffic(key):
-    """HBM bytes per launch measured with rocprofv3 PMC in a separate run of this same
-    command (profiles/pmc_traffic.json); None if no measurement is on record."""
+def pmc_traffic(key, kernel_prefix):
+    """HBM bytes per launch measured with rocprofv3 PMC in a separate run of this same command
+    (profiles/pmc_traffic.json).  None unless a measurement OF THE KERNEL THAT RAN is on record —
+    an entry taken on another kernel must not go stale silently."""
     try:
         rec = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text()).get(key)
-        return float(rec["bytes_per_launch"]) if rec else None
+        if rec and str(rec.get("kernel", "")).startswith(kernel_prefix):
+            return float(rec["bytes_per_launch"])
     except Exception:  # noqa: BLE001
-        return None
+        pass
+    return None
 
 
 def log(*a):
@@ -57,13 +73,15 @@ def log(*a):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="ucc_hybrid", choices=["ucc_hybrid", "ucc_colbert", "synth10m"])
+    ap.add_argument("--windows", type=int, default=5, help="timed regions of --steps steps each (median is reported)")
+    ap.add_argument("--workload", default="ucc_hybrid", choices=["ucc_hybrid", "synth10m"])
     ap.add_argument("--shard", default="auto", choices=["auto", "queries", "corpus"])
     ap.add_argument("--repeat", type=int, default=32, help="ucc_hybrid: the query set is tiled this many times per step")
     ap.add_argument("--synth-rows", type=int, default=10_000_000)
     ap.add_argument("--synth-batch", type=int, default=8)
+    ap.add_argument("--no-extras", action="store_true", help="skip ucc_colbert / full_hybrid_rerank / api / hbm_scan")
     ap.add_argument("--no-hbm-scan", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -71,24 +89,35 @@ def parse():
 
 
 # ---------------------------------------------------------------------------
-def build_ucc(device: int, colbert: bool = False):
-    """UCC-en corpus -> dense matrix (stand-in BGE embeddings), BM25 index, query set."""
-    from legal_rag_amd import _native, text
+# corpora (host side) and their device-resident form
+# ---------------------------------------------------------------------------
+def build_corpus(lang: str, colbert: bool = False):
+    """Law text fixture -> dense matrix (stand-in BGE embeddings), BM25 index, query set
+    [, ColBERT token store]."""
+    from legal_rag_amd import text
     from legal_rag_amd.bm25_model import BM25Okapi
     from legal_rag_amd.encoders import HashingEmbedder
     from legal_rag_amd.evaluation import synthetic_queries
     from legal_rag_amd.retrieval.corpus_loader import load_chunks_from_dir
 
-    chunks = load_chunks_from_dir(str(ROOT / "tests" / "golden" / "corpus"), "law_en.jsonl")
+    chunks = load_chunks_from_dir(str(ROOT / "tests" / "golden" / "corpus"), f"law_{lang}.jsonl")
     emb = HashingEmbedder(dim=768)
     X = emb.encode([c.text for c in chunks])
-    corpus_tokens = [text.tokenize_en(c.text) for c in chunks]
+    # index side: English = lower-cased regex words, Chinese = jieba (bm25_builder.py:39-44).  jieba is
+    # absent offline: the one-character stand-in is an explicit choice here and is reported (zh_exact).
+    zh_mode = None if text.zh_exact() else "char"
+    if lang == "en":
+        corpus_tokens = [text.tokenize_en(c.text) for c in chunks]
+    else:
+        corpus_tokens = [text.jieba_cut(c.text, zh_mode) for c in chunks]
     bm = BM25Okapi(corpus_tokens)
     qs = synthetic_queries(chunks, seed=0)
     Q = emb.encode_queries([q for q, _, _ in qs])
-    q_tokens = [text.jieba_cut(q) for q, _, _ in qs]   # bm25_retriever.py:73 (not lower-cased)
+    q_tokens = [text.jieba_cut(q, zh_mode) for q, _, _ in qs]   # bm25_retriever.py:73 (not lower-cased)
     q_tid = [bm.term_ids(t) for t in q_tokens]
-    W = dict(chunks=chunks, X=X, bm=bm, corpus_tokens=corpus_tokens, queries=qs, Q=Q, q_tokens=q_tokens, q_tid=q_tid)
+    W = dict(lang=lang, chunks=chunks, X=X, bm=bm, corpus_tokens=corpus_tokens, queries=qs, Q=Q, q_tokens=q_tokens,
+             q_tid=q_tid, zh_exact=bool(lang == "en" or text.zh_exact()),
+             bm25_tokenizer="en_regex" if lang == "en" else text.tokenizer_id(zh_mode))
     if colbert:
         from legal_rag_amd.encoders import HashingTokenEmbedder
         te = HashingTokenEmbedder()
@@ -97,6 +126,53 @@ def build_ucc(device: int, colbert: bool = False):
         W["doc_ptr"] = np.concatenate([[0], np.cumsum([m.shape[0] for m in mats])]).astype(np.int64)
         W["Qtok"] = np.stack([te.encode_query(q.strip()) for q, _, _ in qs]).astype(np.float32)
     return W
+
+
+class Resident:
+    """One corpus in HBM: the three channel indexes, the engine over them and a query batch."""
+
+    def __init__(self, torch, W, local, *, rep=1, colbert=False, lo=0, hi=None):
+        from legal_rag_amd import _native
+        from legal_rag_amd.retrieval.engine import HybridEngine
+        device = torch.device("cuda", local)
+        n = W["X"].shape[0]
+        hi = n if hi is None else hi
+        self.W, self.lo, self.hi = W, lo, hi
+        self.dense = _native.DenseIndex(W["X"][lo:hi], device=local)
+        bm = W["bm"]
+        if (lo, hi) != (0, n):
+            # doc-partitioned postings, GLOBAL idf / avgdl (SURVEY.md §8e)
+            tp, pd, pt, idf, dl = bm.to_csr()
+            keep = (pd >= lo) & (pd < hi)
+            cnt = np.zeros(len(tp), dtype=np.int64)
+            term_of = np.repeat(np.arange(len(tp) - 1), np.diff(tp))
+            np.add.at(cnt, term_of[keep] + 1, 1)
+            self.bm25 = _native.BM25Index(np.cumsum(cnt), pd[keep] - lo, pt[keep], idf, dl[lo:hi], float(bm.avgdl),
+                                          bm.k1, bm.b, device=local)
+        else:
+            self.bm25 = bm.gpu(local)
+        self.maxsim = _native.MaxSimIndex(W["D"], W["doc_ptr"], device=local) if colbert else None
+        self.eng = HybridEngine(self.dense, self.bm25, self.maxsim, device=local)
+        tids = W["q_tid"] * rep
+        q_terms_h, self.q_ptr_h = _native.BM25Index.pack_queries(tids)
+        self.q_emb = torch.from_numpy(np.tile(W["Q"], (rep, 1))).to(device)
+        self.q_terms = torch.from_numpy(q_terms_h).to(device)
+        self.q_ptr = torch.from_numpy(self.q_ptr_h).to(device)
+        self.q_tok = torch.from_numpy(np.tile(W["Qtok"], (rep, 1, 1))).to(device) if colbert else None
+        self.nq = int(self.q_emb.shape[0])
+        self.nq0 = len(W["queries"])
+
+    def reserve(self, k):
+        self.eng.reserve(self.nq, k, int(self.q_ptr_h[-1]))
+
+    def search_batch(self, params, k):
+        return self.eng.search_batch(params, k, q_emb=self.q_emb, q_terms=self.q_terms, q_ptr=self.q_ptr,
+                                     q_tok=self.q_tok)
+
+    def close(self):
+        self.dense.close()
+        if self.maxsim is not None:
+            self.maxsim.close()
 
 
 def hybrid_recall(ids_top, counts, chunks, queries, k=10):
@@ -109,12 +185,23 @@ def hybrid_recall(ids_top, counts, chunks, queries, k=10):
     return tot / max(len(queries), 1)
 
 
-def oracle_pipeline(W, qi_list, k=10):
-    """CPU oracle of the same step for the listed queries -> list of id lists."""
+# ---------------------------------------------------------------------------
+# CPU oracle of the same steps (checker + cpu_baseline only)
+# ---------------------------------------------------------------------------
+def oracle_bm25(W):
+    if "_oracle_bm25" not in W:
+        from oracle import bm25 as OB
+        W["_oracle_bm25"] = OB.BM25Okapi(W["corpus_tokens"])
+    return W["_oracle_bm25"]
+
+
+def oracle_pipeline(W, qi_list, k=10, ce=None, beta=0.35, top_n=30):
+    """CPU oracle for the listed queries -> list of id lists (after the min_final filter and,
+    when `ce` (f64 [nq, n]) is given, the rerank blend)."""
     from oracle import bm25 as OB
     from oracle import dense as OD
     from oracle import fusion as OF
-    ob = W["_oracle_bm25"]
+    ob = oracle_bm25(W)
     S, I = OD.flatip_topk(W["X"], W["Q"][qi_list], k)
     out = []
     for j, qi in enumerate(qi_list):
@@ -127,23 +214,31 @@ def oracle_pipeline(W, qi_list, k=10):
             c = [(int(i), float(np.float32(s))) for s, i in zip(cs[0], ci[0]) if i >= 0]
         fused = OF.fuse(d, b, c, {})
         fused = [h for h in fused if h["score"] >= 0.2]
+        if ce is not None and fused:
+            raw = [float(ce[qi, h["id"]]) for h in fused[:top_n]]
+            fused = OF.rerank_blend(fused, raw, beta)
         out.append([h["id"] for h in fused[:k]])
     return out
 
 
+def agreement(ids, cnt, exp, sample, k):
+    same = 0
+    for j, qi in enumerate(sample):
+        got = [int(x) for x in ids[qi, :min(int(cnt[qi]), k)]]
+        same += int(got == exp[j])
+    return same / max(len(sample), 1)
+
+
 def cpu_baseline(W, seconds: float):
-    from oracle import bm25 as OB
     try:
         from threadpoolctl import threadpool_info
         blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:  # noqa: BLE001
         blas_threads = os.cpu_count() or 1
-    W["_oracle_bm25"] = OB.BM25Okapi(W["corpus_tokens"])
+    oracle_bm25(W)
     nq = len(W["queries"])
-    done = 0
+    done, pos, chunk = 0, 0, 64
     t0 = time.perf_counter()
-    chunk = 64
-    pos = 0
     while True:
         idx = [(pos + j) % nq for j in range(chunk)]
         oracle_pipeline(W, idx)
@@ -159,6 +254,200 @@ def cpu_baseline(W, seconds: float):
 
 
 # ---------------------------------------------------------------------------
+# timing helpers
+# ---------------------------------------------------------------------------
+def timed_windows(torch, dist, world, device, step, steps, warmup, windows):
+    """`windows` timed regions of exactly `steps` steps, each bracketed by barrier +
+    synchronize on both sides; per window the MAX over ranks.  Returns seconds per window."""
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    out = []
+    for _ in range(max(1, windows)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        out.append(dt)
+    return out
+
+
+def window_stats(dts, steps):
+    ms = [d / steps * 1e3 for d in dts]
+    med = statistics.median(ms)
+    return {"windows": len(ms), "steps_per_window": steps, "ms_per_step": [round(m, 6) for m in ms],
+            "median": med, "min": min(ms), "max": max(ms), "spread_pct": 100.0 * (max(ms) - min(ms)) / med}
+
+
+def event_ms(torch, fn, reps):
+    """Mean milliseconds of fn() on torch's current stream (the engine launches there)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def maxsim_roofline(ms, tokens, nq, q_len=32, dim=128, note=""):
+    flops = 2.0 * q_len * dim * tokens * nq
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "maxsim_scores_blocked_kernel + rowscores_topk_kernel (v_mfma_f32_16x16x4_f32)",
+            "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
+            "traffic": None, "launch_ms": ms, "algorithmic_flops": flops,
+            "algorithmic_bytes": float(tokens) * dim * 4 + float(nq) * q_len * dim * 4, "note": note}
+
+
+# ---------------------------------------------------------------------------
+# extra objects (rank 0)
+# ---------------------------------------------------------------------------
+def run_ucc_colbert(torch, local, params, K, steps):
+    """BASELINE configs[2]: UCC-en, dense + BM25 + ColBERT MaxSim hybrid fusion top-10."""
+    W = build_corpus("en", colbert=True)
+    R = Resident(torch, W, local, rep=1, colbert=True)
+    R.reserve(K)
+    device = torch.device("cuda", local)
+    dts = timed_windows(torch, None, 1, device, lambda: R.search_batch(params, K), steps, 2, 3)
+    st = window_stats(dts, steps)
+    res = R.search_batch(params, K)
+    torch.cuda.synchronize()
+    ids, cnt = res.ids[:, :K].cpu().numpy(), res.count.cpu().numpy()
+    sample = list(range(0, R.nq0, max(1, R.nq0 // 32)))
+    tokens = int(W["doc_ptr"][-1])
+    ms = event_ms(torch, lambda: R.eng.colbert_topk(R.q_tok, K), max(3, min(steps, 10)))
+    out = {"workload": "UCC-en 591 chunks, dense(768-d FlatIP)+BM25+ColBERT MaxSim hybrid fusion top-10 "
+                       "(BASELINE configs[2])",
+           "value": R.nq / (st["median"] * 1e-3), "unit": "queries/s", "queries_per_step": R.nq, "timing": st,
+           "recall_at_10": hybrid_recall(ids, cnt, W["chunks"], W["queries"], K),
+           "agreement_at_10_vs_oracle": agreement(ids, cnt, oracle_pipeline(W, sample, K), sample, K),
+           "colbert_doc_tokens": tokens, "maxsim_gflop_per_query": 2.0 * 32 * 128 * tokens / 1e9,
+           "roofline": maxsim_roofline(ms, tokens, R.nq, note="MaxSim channel (scores + top-k launches), HIP events")}
+    R.close()
+    return out
+
+
+def run_full_hybrid_rerank(torch, local, K, steps):
+    """BASELINE configs[3] on ONE GPU: Civil-Code-zh + UCC-en behind language routing
+    (by_lang_retriever.py:21-29), the reference's default hybrid (config.py:97,119: ColBERT and
+    rerank ON): dense + BM25 + ColBERT -> fuse -> min_final filter -> rerank blend.  The
+    cross-encoder forward is PyTorch in production; here its scores are a deterministic stand-in
+    matrix CE[query, chunk] resident in HBM, gathered per candidate list on device."""
+    from legal_rag_amd import _native
+    device = torch.device("cuda", local)
+    params = _native.make_fuse_params(w_dense=0.6, w_bm25=0.4, w_colbert=0.35, min_final_score=0.2)
+    beta, top_n = 0.35, 30
+    langs = {}
+    for lang in ("zh", "en"):
+        W = build_corpus(lang, colbert=True)
+        R = Resident(torch, W, local, rep=1, colbert=True)
+        R.reserve(K)
+        # stand-in cross-encoder: a smooth function of the stand-in embeddings, plus a per-pair jitter
+        ce = torch.sigmoid(4.0 * (R.q_emb.double() @ torch.from_numpy(W["X"]).to(device).double().T))
+        g = torch.Generator(device=device).manual_seed(7 if lang == "zh" else 11)
+        ce = (ce + 1e-6 * torch.rand(ce.shape, generator=g, device=device, dtype=torch.float64)).contiguous()
+        langs[lang] = (W, R, ce)
+
+    def one(lang):
+        W, R, ce = langs[lang]
+        res = R.search_batch(params, K)
+        ce_raw = torch.gather(ce, 1, res.ids[:, :top_n].clamp(min=0)).contiguous()
+        return R.eng.rerank_blend(res, ce_raw, beta)
+
+    def step():
+        for lang in langs:
+            one(lang)
+
+    dts = timed_windows(torch, None, 1, device, step, steps, 2, 3)
+    st = window_stats(dts, steps)
+    nq = sum(R.nq for _, R, _ in langs.values())
+    per_lang, ms_total, tok_q = {}, 0.0, 0.0
+    for lang, (W, R, ce) in langs.items():
+        res = one(lang)
+        torch.cuda.synchronize()
+        ids, cnt = res.ids[:, :K].cpu().numpy(), res.count.cpu().numpy()
+        sample = list(range(0, R.nq0, max(1, R.nq0 // 24)))
+        exp = oracle_pipeline(W, sample, K, ce=ce.cpu().numpy(), beta=beta, top_n=top_n)
+        tokens = int(W["doc_ptr"][-1])
+        ms = event_ms(torch, lambda R=R: R.eng.colbert_topk(R.q_tok, K), 5)
+        ms_total += ms
+        tok_q += float(tokens) * R.nq
+        per_lang[lang] = {"chunks": len(W["chunks"]), "queries": R.nq, "colbert_doc_tokens": tokens,
+                          "recall_at_10": hybrid_recall(ids, cnt, W["chunks"], W["queries"], K),
+                          "agreement_at_10_vs_oracle": agreement(ids, cnt, exp, sample, K),
+                          "bm25_tokenizer": W["bm25_tokenizer"], "zh_exact": W["zh_exact"], "maxsim_ms": ms}
+    roof = maxsim_roofline(ms_total, tok_q / nq, nq,
+                           note="MaxSim launches of both languages (dominant kernel of this step), HIP events")
+    for _, R, _ in langs.values():
+        R.close()
+    return {"workload": "Civil-Code-zh (1 260 chunks) + UCC-en (591 chunks), language-routed, dense+BM25+ColBERT -> "
+                        "fuse -> min_final -> rerank blend (stand-in cross-encoder scores resident), top-10, 1 GPU "
+                        "(BASELINE configs[3] without the multi-GPU part)",
+            "value": nq / (st["median"] * 1e-3), "unit": "queries/s", "queries_per_step": nq, "timing": st,
+            "rerank": {"beta": beta, "top_n": top_n, "cross_encoder": "stand-in scores resident in HBM"},
+            "per_lang": per_lang, "roofline": roof}
+
+
+def run_api(torch, local):
+    """The reference-shaped Python API end to end on the UCC-en corpus: builders -> artifacts ->
+    HybridRetriever.search / search_batch, stand-in encoders (hashing) and stand-in cross-encoder,
+    everything a caller pays: tokenisation, encoder, kernels, D2H, RetrievalHit construction."""
+    from legal_rag_amd.config import AppConfig
+    from legal_rag_amd.evaluation import synthetic_queries
+    from legal_rag_amd.retrieval.builders.bm25_builder import build_bm25_index
+    from legal_rag_amd.retrieval.builders.colbert_builder import build_colbert_index
+    from legal_rag_amd.retrieval.builders.faiss_builder import build_faiss_index
+    from legal_rag_amd.retrieval.corpus_loader import load_chunks_from_dir
+    from legal_rag_amd.retrieval.hybrid_retriever import HybridRetriever
+
+    out = {"note": "stand-in encoders (hashing) and stand-in cross-encoder: the BERT forwards of a deployment are "
+                   "not in these numbers; everything else a caller of the Python API pays is"}
+    with tempfile.TemporaryDirectory(prefix="amdr_bench_") as tmp:
+        cfg = AppConfig.for_data_dir(tmp, "en")
+        cfg.retrieval.encoder_backend = "hashing"
+        cfg.retrieval.rerank_ce_model = "hashing"
+        cfg.retrieval.device = local
+        cfg.retrieval.enable_graph = False
+        chunks = load_chunks_from_dir(str(ROOT / "tests" / "golden" / "corpus"), "law_en.jsonl")
+        build_faiss_index(cfg, chunks)
+        build_bm25_index(cfg, chunks)
+        build_colbert_index(cfg, chunks)
+        qs = [q for q, _, _ in synthetic_queries(chunks, seed=0)]
+        for name, colbert, rerank in (("search_default_hybrid", True, True), ("search_dense_bm25", False, False)):
+            cfg.retrieval.enable_colbert, cfg.retrieval.enable_rerank = colbert, rerank
+            r = HybridRetriever(cfg)
+            for q in qs[:20]:
+                r.search(q, top_k=10)
+            lat = []
+            for q in qs[20:320]:
+                t = time.perf_counter()
+                r.search(q, top_k=10)
+                lat.append((time.perf_counter() - t) * 1e3)
+            lat.sort()
+            out[name] = {"channels": "dense+bm25" + ("+colbert" if colbert else "") + (" + rerank" if rerank else ""),
+                         "calls": len(lat), "p50_ms": lat[len(lat) // 2], "p99_ms": lat[int(len(lat) * 0.99)],
+                         "mean_ms": sum(lat) / len(lat), "queries_per_s": 1e3 * len(lat) / sum(lat)}
+            if not colbert:
+                r.search_batch(qs[:64], top_k=10)
+                t = time.perf_counter()
+                hits = r.search_batch(qs, top_k=10)
+                dt = time.perf_counter() - t
+                out["search_batch_dense_bm25"] = {"queries": len(qs), "seconds": dt, "queries_per_s": len(qs) / dt,
+                                                  "hits_returned": sum(len(h) for h in hits)}
+    return out
+
+
 def synth_matrix(torch, n, d, device, seed=1234):
     """rng(seed) normal rows, L2-normalised, generated in HBM in 1M-row chunks."""
     g = torch.Generator(device=device)
@@ -173,16 +462,19 @@ def synth_matrix(torch, n, d, device, seed=1234):
     return X
 
 
+def synth_queries(torch, device, d=768, n=1024):
+    g = torch.Generator(device=device)
+    g.manual_seed(4321)
+    Q = torch.randn((n, d), generator=g, device=device, dtype=torch.float32)
+    Q /= Q.norm(dim=1, keepdim=True)
+    return Q
+
+
 def run_hbm_scan(torch, device, n, d, batches, steps, warmup, k=10):
     from legal_rag_amd import _native
     X = synth_matrix(torch, n, d, device)
-    g = torch.Generator(device=device)
-    g.manual_seed(4321)
-    Q = torch.randn((1024, d), generator=g, device=device, dtype=torch.float32)
-    Q /= Q.norm(dim=1, keepdim=True)
-    out = []
-    for B in batches:
-        out.append(_hbm_scan_one(torch, _native, device, X, Q, n, d, B, steps, warmup, k))
+    Q = synth_queries(torch, device, d)
+    out = [_hbm_scan_one(torch, _native, device, X, Q, n, d, B, steps, warmup, k) for B in batches]
     del X
     torch.cuda.empty_cache()
     return out
@@ -205,6 +497,7 @@ def _hbm_scan_one(torch, _native, device, X, Q, n, d, B, steps, warmup, k):
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     scan_ms, launches = idx.profile_end()
+    plan = idx.plan_info(B, k)
     # parity on a prefix: oracle over the first 200k rows must agree with a scan of that prefix
     from oracle import dense as OD
     npre = min(n, 200_000)
@@ -214,17 +507,16 @@ def _hbm_scan_one(torch, _native, device, X, Q, n, d, B, steps, warmup, k):
     es, ei = OD.flatip_topk(X[:npre].cpu().numpy(), Qh, k)
     agree = float(np.mean(gi == ei))
     maxerr = float(np.max(np.abs(gs - es)))
-    batched = B >= 5  # 32-query-tile fp32-MFMA form: scores S[B, n] are written once and read once
+    kernel = plan.split(" ")[0].split("<")[0]
+    batched = kernel != "dense_scan_topk_kernel"  # scores S[B, n] are written once and read once
     bytes_per_launch = float(n) * d * 4 + B * d * 4 + (float(n) * B * 4 if batched else B * k * 8)
     per_launch_ms = scan_ms / max(launches, 1)
     achieved = bytes_per_launch / (per_launch_ms * 1e-3) / 1e9
-    out = {"workload": f"synthetic {n}x{d} fp32 rows in HBM, {B} queries/scan, top-{k}",
-           "kernel": "dense_mfma_scores_kernel" if batched else "dense_scan_topk_kernel",
+    out = {"workload": f"synthetic {n}x{d} fp32 rows in HBM, {B} queries/scan, top-{k}", "kernel": kernel, "plan": plan,
            "queries_per_s": B * steps / wall, "ms_per_scan_wall": wall / steps * 1e3,
            "scan_kernel_ms": per_launch_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
            "achieved_GBs": achieved, "peak_GBs": HBM_PEAK_GBS, "frac": achieved / HBM_PEAK_GBS,
-           "traffic": pmc_traffic(f"synth10m_b{B}/" + ("dense_mfma_scores_kernel" if batched else "dense_scan_topk_kernel"))
-           if (n == 10_000_000 and d == 768) else None,
+           "traffic": pmc_traffic(f"synth10m_b{B}", kernel) if (n == 10_000_000 and d == 768) else None,
            "f32_TFLOPs": 2.0 * n * d * B / (per_launch_ms * 1e-3) / 1e12,
            "oracle_prefix_rows": npre, "oracle_id_agreement": agree, "oracle_max_abs_err": maxerr}
     idx.close()
@@ -232,14 +524,91 @@ def _hbm_scan_one(torch, _native, device, X, Q, n, d, B, steps, warmup, k):
     return out
 
 
-def with_colbert_tokens(result, scope):
-    """Annotate the colbert workload with the MaxSim work per step (no timing here)."""
-    W = scope.get("W")
-    if isinstance(W, dict) and "doc_ptr" in W and isinstance(result, dict) and "config" in result:
-        tokens = int(W["doc_ptr"][-1])
-        result["config"]["colbert_doc_tokens"] = tokens
-        result["config"]["maxsim_gflop_per_query"] = 2.0 * 32 * 128 * tokens / 1e9
-    return False
+def run_scale_synth10m(torch, dist, world, rank, local, device, n_total, B, steps, warmup, K=10):
+    """The north_star multi-GPU layout on the synthetic matrix: rows sharded over the ranks, every
+    rank scans its shard (HIP), ONE all_gather_into_tensor of the packed per-shard top-k (RCCL
+    over xGMI), merge_parts_kernel on every rank.  Strong scaling of one n_total-row corpus."""
+    from legal_rag_amd import _native
+    from legal_rag_amd.retrieval import sharding
+    lo, hi = sharding.shard_bounds(n_total, world)[rank]
+    X = synth_matrix(torch, hi - lo, 768, device, seed=1234 + rank)
+    Q = synth_queries(torch, device)
+    idx = _native.DenseIndex(device_ptr=X.data_ptr(), n=hi - lo, dim=768, device=local, keepalive=X)
+    idx.reserve(B, K)
+    s = torch.empty((B, K), dtype=torch.float32, device=device)
+    i = torch.empty((B, K), dtype=torch.int64, device=device)
+    merged = {}
+
+    def step_at(w):
+        off = (w * B) % (1024 - B + 1)
+        idx.search_device(Q[off:].data_ptr(), B, K, s.data_ptr(), i.data_ptr(),
+                          int(torch.cuda.current_stream().cuda_stream))
+        merged["out"] = sharding.exchange_topk([(s, i)], lo)[0] if world > 1 else (s, i)
+
+    cnt = {"w": 0}
+
+    def step():
+        step_at(cnt["w"])
+        cnt["w"] += 1
+
+    for _ in range(warmup):
+        step()
+    idx.profile_begin(steps * 3)
+    dts = timed_windows(torch, dist, world, device, step, steps, 0, 3)
+    scan_ms, launches = idx.profile_end()
+    st = window_stats(dts, steps)
+    per_scan = scan_ms / max(launches, 1)
+    # agreement with an UNSHARDED oracle on a prefix: the first rows of every shard, gathered on rank 0
+    npre = 20_000
+    step_at(0)
+    ms_, mi_ = merged["out"]
+    torch.cuda.synchronize()
+    pre = _native.DenseIndex(device_ptr=X.data_ptr(), n=min(npre, hi - lo), dim=768, device=local, keepalive=X)
+    ps, pi = pre.search(Q[:B].cpu().numpy(), K)
+    pre.close()
+    local_ok = 1.0
+    if world > 1:
+        # every shard's prefix result must be consistent with the merged global list: a merged hit that
+        # falls inside this shard's prefix must appear in the prefix scan with the same score
+        mi_h, ms_h = mi_.cpu().numpy(), ms_.cpu().numpy()
+        ok = tot = 0
+        for b in range(B):
+            for gid, sc in zip(mi_h[b], ms_h[b]):
+                if lo <= gid < lo + min(npre, hi - lo):
+                    tot += 1
+                    j = np.where(pi[b] == gid - lo)[0]
+                    ok += int(len(j) == 1 and abs(float(ps[b, j[0]]) - float(sc)) <= 1e-4)
+        t = torch.tensor([ok, tot], dtype=torch.float64, device=device)
+        dist.all_reduce(t)
+        local_ok = float(t[0].item() / t[1].item()) if t[1].item() > 0 else 1.0
+    scans = torch.tensor([per_scan], dtype=torch.float64, device=device)
+    if world > 1:
+        allscan = [torch.zeros_like(scans) for _ in range(world)]
+        dist.all_gather(allscan, scans)
+        per_rank = [float(x.item()) for x in allscan]
+    else:
+        per_rank = [per_scan]
+    plan = idx.plan_info(B, K)
+    kernel = plan.split(" ")[0].split("<")[0]
+    batched = kernel != "dense_scan_topk_kernel"
+    bytes_per_launch = float(hi - lo) * 768 * 4 + B * 768 * 4 + (float(hi - lo) * B * 4 if batched else B * K * 8)
+    achieved = bytes_per_launch / (per_scan * 1e-3) / 1e9
+    out = {"workload": f"synthetic {n_total}x768 fp32 chunk matrix row-sharded over {world} GPU(s), {B} queries/scan, "
+                       f"top-{K} (BASELINE configs[4]); per scan: HIP scan of the shard -> all_gather_into_tensor "
+                       f"of {B}x{K} packed (score, global id) per rank -> merge_parts_kernel",
+           "value": B / (st["median"] * 1e-3), "unit": "queries/s", "scaling": "strong", "timing": st,
+           "scan_kernel_ms_per_rank": per_rank,
+           "collective_plus_merge_ms": max(0.0, st["median"] - max(per_rank)),
+           "exchange_bytes_per_rank_per_scan": B * K * 16,
+           "merged_hits_consistent_with_shard_prefix_scans": local_ok,
+           "roofline": {"bound": "hbm", "kernel": kernel, "plan": plan, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launch_ms": per_scan,
+                        "algorithmic_bytes": bytes_per_launch,
+                        "note": "per-rank scan of this rank's shard (rank 0); collective and merge are not in it"}}
+    idx.close()
+    del X
+    torch.cuda.empty_cache()
+    return out
 
 
 # ---------------------------------------------------------------------------
@@ -271,95 +640,50 @@ def main():
 
     from legal_rag_amd import _native
     from legal_rag_amd.retrieval import sharding
-    from legal_rag_amd.retrieval.engine import HybridEngine
 
     _native.load()
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     result = {}
-    if a.workload in ("ucc_hybrid", "ucc_colbert"):
+    if a.workload == "ucc_hybrid":
         K = 10
-        with_colbert = a.workload == "ucc_colbert"
-        W = build_ucc(local, colbert=with_colbert)
-        nq0 = len(W["queries"])
-        rep = 1 if with_colbert else max(1, a.repeat)
+        W = build_corpus("en")
+        rep = max(1, a.repeat)
         shard = "queries" if a.shard == "auto" else a.shard
         n = W["X"].shape[0]
-        if shard == "corpus" and world > 1:
-            lo, hi = sharding.shard_bounds(n, world)[rank]
-        else:
-            lo, hi = 0, n
-        # ---- index in HBM (this rank's rows) -------------------------------
-        dense = _native.DenseIndex(W["X"][lo:hi], device=local)
-        bm = W["bm"]
-        if (lo, hi) != (0, n):
-            # doc-partitioned postings, GLOBAL idf / avgdl
-            tp, pd, pt, idf, dl = bm.to_csr()
-            keep = (pd >= lo) & (pd < hi)
-            cnt = np.zeros(len(tp), dtype=np.int64)
-            term_of = np.repeat(np.arange(len(tp) - 1), np.diff(tp))
-            np.add.at(cnt, term_of[keep] + 1, 1)
-            bmi = _native.BM25Index(np.cumsum(cnt), pd[keep] - lo, pt[keep], idf, dl[lo:hi], float(bm.avgdl),
-                                    bm.k1, bm.b, device=local)
-        else:
-            bmi = bm.gpu(local)
-        msi = None
-        q_tok = None
-        if with_colbert:
-            if (lo, hi) != (0, n):
-                raise SystemExit("ucc_colbert: use --shard queries")
-            msi = _native.MaxSimIndex(W["D"], W["doc_ptr"], device=local)
-            q_tok = torch.from_numpy(np.tile(W["Qtok"], (rep, 1, 1))).to(device)
-        eng = HybridEngine(dense, bmi, msi, device=local)
-        # ---- this rank's query batch, resident in HBM ----------------------
-        Qh = np.tile(W["Q"], (rep, 1))
-        tids = W["q_tid"] * rep
-        q_terms_h, q_ptr_h = _native.BM25Index.pack_queries(tids)
-        q_emb = torch.from_numpy(Qh).to(device)
-        q_terms = torch.from_numpy(q_terms_h).to(device)
-        q_ptr = torch.from_numpy(q_ptr_h).to(device)
-        nq = q_emb.shape[0]
+        lo, hi = sharding.shard_bounds(n, world)[rank] if (shard == "corpus" and world > 1) else (0, n)
+        R = Resident(torch, W, local, rep=rep, lo=lo, hi=hi)
+        nq, nq0 = R.nq, R.nq0
         params = _native.make_fuse_params(min_final_score=0.2)  # reference defaults (config.py:92-94,128)
-        eng.reserve(nq, K, int(q_ptr_h[-1]))
+        R.reserve(K)
+        last = {}
 
         def step():
             if shard == "corpus" and world > 1:
-                d = eng.dense_topk(q_emb, K)
-                b = eng.bm25_topk(q_terms, q_ptr, K)
+                d = R.eng.dense_topk(R.q_emb, K)
+                b = R.eng.bm25_topk(R.q_terms, R.q_ptr, K)
                 (ds, di), (bs, bi) = sharding.exchange_topk([d, b], lo)
-                return eng.fuse(params, nq, (ds, di), (bs, bi), None)
-            return eng.search_batch(params, K, q_emb=q_emb, q_terms=q_terms, q_ptr=q_ptr, q_tok=q_tok)
+                last["res"] = R.eng.fuse(params, nq, (ds, di), (bs, bi), None)
+            else:
+                last["res"] = R.search_batch(params, K)
 
         for _ in range(a.warmup):
             step()
-        barrier()
-        dense.profile_begin(a.steps)
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            res = step()
-        barrier()
-        dt = time.perf_counter() - t0
-        scan_ms, launches = dense.profile_end()
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+        R.dense.profile_begin(a.steps * max(1, a.windows))
+        dts = timed_windows(torch, dist, world, device, step, a.steps, 0, a.windows)
+        scan_ms, launches = R.dense.profile_end()
+        st = window_stats(dts, a.steps)
         queries_per_step_total = nq * (world if shard == "queries" else 1)
-        value = queries_per_step_total * a.steps / dt
-
+        value = queries_per_step_total / (st["median"] * 1e-3)
+        res = last["res"]
         ids = res.ids[:, :K].cpu().numpy()
         cnt = res.count.cpu().numpy()
         rec = hybrid_recall(ids[:nq0], cnt[:nq0], W["chunks"], W["queries"], K)
         # ---- single-query latency through the same kernels (B = 1) ----------
         lat_us = lat_p50 = lat_p99 = lat_graph_p50 = lat_graph_p99 = None
         if rank == 0:
-            q1 = q_emb[:1].contiguous()
-            t1 = q_terms[: int(q_ptr_h[1])].contiguous() if q_ptr_h[1] > 0 else q_terms[:1]
-            p1 = q_ptr[:2].contiguous()
+            eng = R.eng
+            q1 = R.q_emb[:1].contiguous()
+            t1 = R.q_terms[: int(R.q_ptr_h[1])].contiguous() if R.q_ptr_h[1] > 0 else R.q_terms[:1]
+            p1 = R.q_ptr[:2].contiguous()
             for _ in range(20):
                 eng.search_batch(params, K, q_emb=q1, q_terms=t1, q_ptr=p1)
             torch.cuda.synchronize()
@@ -388,151 +712,90 @@ def main():
 
         rows_local = hi - lo
         d = W["X"].shape[1]
-        # Dominant kernel of the step = dense_mfma_scores_kernel: [rows x d] . [d x nq] in exact fp32 on
-        # the matrix pipe.  At UCC-en size X (1.8 MB) is L2-resident, so the bound is the fp32 MFMA rate
+        # Dominant kernel of the step = the dense scores kernel: [rows x d] . [d x nq] in exact fp32 on the
+        # matrix pipe.  At UCC-en size X (1.8 MB) is L2-resident, so the bound is the fp32 MFMA rate
         # (157.3 TFLOP/s = the fp32 vector rate, MI355X_MICROARCH.md), not HBM.
+        plan = R.dense.plan_info(nq, K)
+        kernel = plan.split(" ")[0]
         flops_per_launch = 2.0 * rows_local * d * nq
         per_launch_ms = scan_ms / max(launches, 1)
         achieved = flops_per_launch / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
-        roofline = {"bound": "mfma", "kernel": "dense_mfma_scores_kernel (v_mfma_f32_16x16x4_f32, exact fp32)",
+        roofline = {"bound": "mfma", "kernel": f"{kernel} (v_mfma_f32_16x16x4_f32, exact fp32)", "plan": plan,
                     "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / F32_MFMA_PEAK_TFLOPS,
-                    "traffic": pmc_traffic("ucc_hybrid/dense_mfma_scores_kernel") if (not with_colbert and rep == 32
-                                                                                     and shard == "queries") else None,
-                    "launch_ms": per_launch_ms,
+                    "traffic": pmc_traffic("ucc_hybrid", kernel) if (rep == 32 and shard == "queries") else None,
+                    "launch_ms": per_launch_ms, "launches_timed": launches,
                     "algorithmic_flops": flops_per_launch,
                     "algorithmic_bytes": float(rows_local) * d * 4 + nq * d * 4 + float(rows_local) * nq * 4,
-                    "note": "HBM-roofline evidence for the same channel on a 30.7 GB matrix is in hbm_scan"}
-        if with_colbert:
-            # the MaxSim pass dominates this workload: time it on its own (torch events see the stream it runs on)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = max(3, min(a.steps, 10))
-            eng.colbert_topk(q_tok, K)
-            e0.record()
-            for _ in range(reps):
-                eng.colbert_topk(q_tok, K)
-            e1.record()
-            torch.cuda.synchronize()
-            ms_ms = e0.elapsed_time(e1) / reps
-            tokens = int(W["doc_ptr"][-1])
-            ms_flops = 2.0 * q_tok.shape[1] * q_tok.shape[2] * tokens * nq
-            roofline = {"bound": "mfma", "kernel": "maxsim_scores_blocked_kernel + rowscores_topk_kernel (v_mfma_f32_16x16x4_f32)",
-                        "achieved": ms_flops / (ms_ms * 1e-3) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ms_flops / (ms_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, "traffic": None,
-                        "launch_ms": ms_ms, "algorithmic_flops": ms_flops,
-                        "algorithmic_bytes": float(tokens) * q_tok.shape[2] * 4 + float(nq) * q_tok.shape[1] * q_tok.shape[2] * 4,
-                        "note": "MaxSim channel (scores + top-k launches together); the dense channel's kernel is "
-                                "reported by the default workload"}
+                    "note": "HIP events around the scores kernel alone, every timed window; HBM-roofline evidence "
+                            "for the same channel on a 30.7 GB matrix is in hbm_scan"}
         result = {
             "metric": "queries/sec + Recall@10 (hybrid top-10) on UCC-en", "value": value, "unit": "queries/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": st["median"],
             "higher_is_better": True, "scaling": "weak" if shard == "queries" else "strong", "vs_baseline": None,
             "dtype": "f32 dense / f64 bm25+fusion", "data": "UCC-en law text (fixture) with deterministic stand-in "
             "embeddings (no BGE weights offline) and a seeded synthetic query set",
-            "config": {"workload": ("UCC-en 591 chunks, dense(768-d FlatIP)+BM25+ColBERT MaxSim hybrid fusion top-10 "
-                                    "(BASELINE configs[2])" if with_colbert else
-                                    "UCC-en 591 chunks, dense(768-d FlatIP)+BM25 hybrid fusion top-10 "
-                                    "(BASELINE configs[1])"), "queries_per_step_per_gpu": nq, "unique_queries": nq0,
+            "config": {"workload": "UCC-en 591 chunks, dense(768-d FlatIP)+BM25 hybrid fusion top-10 "
+                                   "(BASELINE configs[1])", "queries_per_step_per_gpu": nq, "unique_queries": nq0,
                        "top_k": K, "shard": shard, "fusion": "rrf_norm_blend w=0.6/0.4 alpha=0.5 rrf_k=60 "
                        "min_final=0.2"},
-            "recall_at_10": rec, "latency_b1_us": lat_us, "latency_b1_p50_us": lat_p50, "latency_b1_p99_us": lat_p99,
-            "latency_b1_graph_p50_us": lat_graph_p50, "latency_b1_graph_p99_us": lat_graph_p99,
-            "roofline": roofline,
+            "timing": st, "recall_at_10": rec, "latency_b1_us": lat_us, "latency_b1_p50_us": lat_p50,
+            "latency_b1_p99_us": lat_p99, "latency_b1_graph_p50_us": lat_graph_p50,
+            "latency_b1_graph_p99_us": lat_graph_p99, "roofline": roofline,
         }
         if rank == 0:
             # agreement@10 with the CPU oracle on identical inputs
-            from oracle import bm25 as OB
-            W["_oracle_bm25"] = OB.BM25Okapi(W["corpus_tokens"])
-            sample = list(range(0, nq0, max(1, nq0 // (32 if with_colbert else 256))))
-            exp = oracle_pipeline(W, sample, K)
-            same = 0
-            for j, qi in enumerate(sample):
-                got = [int(x) for x in ids[qi, :min(int(cnt[qi]), K)]]
-                same += int(got == exp[j])
-            result["agreement_at_10_vs_oracle"] = same / len(sample)
-            if not with_colbert and shard == "queries":
+            sample = list(range(0, nq0, max(1, nq0 // 256)))
+            result["agreement_at_10_vs_oracle"] = agreement(ids, cnt, oracle_pipeline(W, sample, K), sample, K)
+            if shard == "queries":
                 # the evaluation depth of the reference (evaluate_retrieval.py: k = 80), one untimed pass
                 K80 = 80
                 s80 = list(range(0, nq0, max(1, nq0 // 64)))
-                r80 = eng.search_batch(params, K80, q_emb=q_emb[:nq0].contiguous(), q_terms=q_terms[: int(q_ptr_h[nq0])],
-                                       q_ptr=q_ptr[: nq0 + 1].contiguous())
+                r80 = R.eng.search_batch(params, K80, q_emb=R.q_emb[:nq0].contiguous(),
+                                         q_terms=R.q_terms[: int(R.q_ptr_h[nq0])], q_ptr=R.q_ptr[: nq0 + 1].contiguous())
                 ids80, cnt80 = r80.ids.cpu().numpy(), r80.count.cpu().numpy()
-                exp80 = oracle_pipeline(W, s80, K80)
-                ok80 = sum(int([int(x) for x in ids80[qi, :min(int(cnt80[qi]), K80)]] == exp80[j])
-                           for j, qi in enumerate(s80))
-                result["agreement_at_80_vs_oracle"] = ok80 / len(s80)
+                result["agreement_at_80_vs_oracle"] = agreement(ids80, cnt80, oracle_pipeline(W, s80, K80), s80, K80)
                 result["recall_at_80"] = hybrid_recall(ids80, cnt80, W["chunks"], W["queries"], K80)
             if not a.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(W, a.cpu_seconds)
-        dense.close()
-        del eng
-    else:
-        K = 10
-        n_total = a.synth_rows
-        B = a.synth_batch
-        # corpus row-sharded over ranks (strong scaling of one 10M-row corpus)
-        lo, hi = sharding.shard_bounds(n_total, world)[rank]
-        X = synth_matrix(torch, hi - lo, 768, device, seed=1234 + rank)
-        g = torch.Generator(device=device)
-        g.manual_seed(4321)
-        Q = torch.randn((1024, 768), generator=g, device=device, dtype=torch.float32)
-        Q /= Q.norm(dim=1, keepdim=True)
-        idx = _native.DenseIndex(device_ptr=X.data_ptr(), n=hi - lo, dim=768, device=local, keepalive=X)
-        idx.reserve(B, K)
-        s = torch.empty((B, K), dtype=torch.float32, device=device)
-        i = torch.empty((B, K), dtype=torch.int64, device=device)
-
-        def step(w):
-            off = (w * B) % (1024 - B + 1)
-            idx.search_device(Q[off:].data_ptr(), B, K, s.data_ptr(), i.data_ptr(),
-                              int(torch.cuda.current_stream().cuda_stream))
-            if world > 1:
-                return sharding.exchange_topk([(s, i)], lo)
-            return [(s, i)]
-
-        for w in range(a.warmup):
-            step(w)
-        barrier()
-        idx.profile_begin(a.steps)
-        t0 = time.perf_counter()
-        for w in range(a.steps):
-            step(w)
-        barrier()
-        dt = time.perf_counter() - t0
-        scan_ms, launches = idx.profile_end()
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        batched = B >= 5  # 32-query-tile fp32-MFMA form: S[B, rows] is written once (and read once by the top-k pass)
-        bytes_per_launch = float(hi - lo) * 768 * 4 + B * 768 * 4 + (float(hi - lo) * B * 4 if batched else B * K * 8)
-        per_launch_ms = scan_ms / max(launches, 1)
-        achieved = bytes_per_launch / (per_launch_ms * 1e-3) / 1e9
-        result = {
-            "metric": "queries/sec, brute-force cosine top-10", "value": B * a.steps / dt, "unit": "queries/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic", "config": {"workload": f"synthetic {n_total}x768 fp32 chunk matrix row-sharded over "
-                                            f"{world} GPU(s), {B} queries/scan, top-10 (BASELINE configs[4])"},
-            "roofline": {"bound": "hbm", "kernel": "dense_mfma_scores_kernel" if batched else "dense_scan_topk_kernel",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(f"synth10m_b{B}/" + ("dense_mfma_scores_kernel" if batched else
-                                                                        "dense_scan_topk_kernel"))
-                         if (world == 1 and n_total == 10_000_000) else None,
-                         "launch_ms": per_launch_ms, "algorithmic_bytes": bytes_per_launch,
-                         "f32_TFLOPs": 2.0 * (hi - lo) * 768 * B / (per_launch_ms * 1e-3) / 1e12},
-        }
-        idx.close()
-        del X
-
-    if with_colbert_tokens(result, locals()):
-        pass
-    if rank == 0 and a.workload == "ucc_hybrid" and not a.no_hbm_scan:
+        R.close()
+        del R
         torch.cuda.empty_cache()
-        try:
-            result["hbm_scan"] = run_hbm_scan(torch, device, a.synth_rows, 768, [4, 32], steps=20, warmup=3)
-        except Exception as e:  # noqa: BLE001 - report, never hide
-            result["hbm_scan"] = {"error": repr(e)}
+        extras = not a.no_extras
+        if rank == 0 and extras and world == 1:
+            for name, fn in (("ucc_colbert", lambda: run_ucc_colbert(torch, local, params, K, max(3, min(a.steps, 10)))),
+                             ("full_hybrid_rerank", lambda: run_full_hybrid_rerank(torch, local, K, max(3, min(a.steps, 10)))),
+                             ("api", lambda: run_api(torch, local))):
+                try:
+                    t0 = time.perf_counter()
+                    result[name] = fn()
+                    log(f"{name}: {time.perf_counter() - t0:.1f}s")
+                except Exception as e:  # noqa: BLE001 - report, never hide
+                    result[name] = {"error": repr(e)}
+                torch.cuda.empty_cache()
+        if world > 1 and extras:
+            # the row-sharded layout under the same launch (every rank takes part)
+            try:
+                sc = run_scale_synth10m(torch, dist, world, rank, local, device, a.synth_rows, 32, 10, 3)
+            except Exception as e:  # noqa: BLE001
+                sc = {"error": repr(e)}
+            if rank == 0:
+                result["scale_synth10m"] = sc
+        if rank == 0 and extras and world == 1 and not a.no_hbm_scan:
+            try:
+                result["hbm_scan"] = run_hbm_scan(torch, device, a.synth_rows, 768, [4, 32], steps=20, warmup=3)
+            except Exception as e:  # noqa: BLE001 - report, never hide
+                result["hbm_scan"] = {"error": repr(e)}
+    else:
+        sc = run_scale_synth10m(torch, dist, world, rank, local, device, a.synth_rows, a.synth_batch, a.steps, a.warmup)
+        result = {"metric": "queries/sec, brute-force cosine top-10", "value": sc["value"], "unit": "queries/s",
+                  "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": sc["timing"]["median"],
+                  "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+                  "data": "synthetic", "config": {"workload": sc["workload"]}, "timing": sc["timing"],
+                  "roofline": sc["roofline"], "scan_kernel_ms_per_rank": sc["scan_kernel_ms_per_rank"],
+                  "collective_plus_merge_ms": sc["collective_plus_merge_ms"],
+                  "merged_hits_consistent_with_shard_prefix_scans": sc["merged_hits_consistent_with_shard_prefix_scans"]}
+
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

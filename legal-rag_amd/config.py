@@ -75,6 +75,7 @@ class RetrievalConfig:
     # --- build-specific knobs (no reference counterpart) ---
     device: int = 0                      # HIP device ordinal of this process
     encoder_backend: str = "auto"        # "auto" | "transformers" | "hashing" (deterministic stand-in)
+    rerank_fp16: bool = False            # cross-encoder in half precision (the reference's CrossEncoder runs fp32)
     zh_tokenizer: str = "jieba"          # "jieba" (raises if Han text meets no segmenter) | "char" (explicit
                                          # opt-in to the inexact one-character stand-in, text.py)
 

@@ -242,17 +242,17 @@ class TransformersColBERT:
 _EMBEDDER_CACHE = {}
 
 
-def get_embedder(model_name: str, backend: str = "auto", dim: int = 768):
+def get_embedder(model_name: str, backend: str = "auto", dim: int = 768, device: Optional[str] = None):
     """Resolve the sentence encoder.  'hashing' -> stand-in; 'transformers' ->
     local checkpoint required; 'auto' -> local checkpoint if `model_name` is a
     directory, else an error naming what is missing (no silent stand-in)."""
-    key = (model_name, backend, dim)
+    key = (model_name, backend, dim, device)
     if key in _EMBEDDER_CACHE:
         return _EMBEDDER_CACHE[key]
     if backend == "hashing":
         m = HashingEmbedder(dim=dim)
     elif os.path.isdir(model_name):
-        m = TransformersBGE(model_name)
+        m = TransformersBGE(model_name, device=device)  # cfg.retrieval.device, not whatever "cuda" defaults to
     else:
         raise RuntimeError(
             f"embedding model '{model_name}' is not a local checkpoint directory and this build has no network; "

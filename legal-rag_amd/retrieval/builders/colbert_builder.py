@@ -29,7 +29,7 @@ def build_colbert_index(cfg, chunks: List[LawChunk], override: bool = False) -> 
     if not any(docs):
         raise RuntimeError("All chunks are empty; cannot build ColBERT index.")
     enc = get_token_encoder(getattr(rcfg, "colbert_model_name", None), str(getattr(rcfg, "encoder_backend", "auto")),
-                            doc_maxlen)
+                            doc_maxlen, device=f"cuda:{int(getattr(rcfg, 'device', 0))}")
     index_path.mkdir(parents=True, exist_ok=True)
     with FileLock(str(index_path / ".colbert_build.lock")):
         out_dir = artifacts.colbert_index_dir(str(index_path), experiment, index_name)

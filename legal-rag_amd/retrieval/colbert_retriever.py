@@ -27,16 +27,16 @@ from ..schemas import LawChunk
 _TOKEN_ENCODERS: Dict[Tuple[str, str, int], object] = {}
 
 
-def get_token_encoder(model_name: Optional[str], backend: str, doc_maxlen: int):
+def get_token_encoder(model_name: Optional[str], backend: str, doc_maxlen: int, device: Optional[str] = None):
     """'hashing' -> deterministic stand-in; a local checkpoint directory -> BERT-style
     ColBERT on PyTorch-ROCm; anything else cannot be had offline and fails loudly."""
-    key = (str(model_name), backend, int(doc_maxlen))
+    key = (str(model_name), backend, int(doc_maxlen), device)
     enc = _TOKEN_ENCODERS.get(key)
     if enc is None:
         if backend == "hashing":
             enc = encoders.HashingTokenEmbedder(doc_maxlen=doc_maxlen)
         elif model_name and os.path.isdir(str(model_name)):
-            enc = encoders.TransformersColBERT(str(model_name), doc_maxlen=doc_maxlen)
+            enc = encoders.TransformersColBERT(str(model_name), doc_maxlen=doc_maxlen, device=device)
         else:
             raise RuntimeError(
                 f"ColBERT checkpoint '{model_name}' cannot be loaded offline (jina-colbert-v2 needs remote code and "
@@ -102,7 +102,8 @@ class ColBERTRetriever:
     def _init_searcher(self) -> None:
         rcfg = self.cfg.retrieval
         self._encoder = get_token_encoder(self.model_name, str(getattr(rcfg, "encoder_backend", "auto")),
-                                          int(getattr(rcfg, "colbert_doc_maxlen", 220)))
+                                          int(getattr(rcfg, "colbert_doc_maxlen", 220)),
+                                          device=f"cuda:{self.device_index}")
         key = (str(self.index_path), self.index_name, str(self.model_name), self.experiment, self.nranks)
         with type(self)._registry_lock:
             if key not in type(self)._searcher_cache:

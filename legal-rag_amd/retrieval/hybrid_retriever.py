@@ -322,8 +322,11 @@ class HybridRetriever:
         t_rerank = None
         if getattr(rcfg, "enable_rerank", False):
             use_llm_rerank = bool(getattr(rcfg, "rerank_use_llm", False))
+            dev = getattr(rcfg, "device", None)
             factory = RerankerFactory(llm=llm if use_llm_rerank else None, cross_model=rcfg.rerank_ce_model,
-                                      llm_threshold=30, use_cache=True)
+                                      llm_threshold=30, use_cache=True,
+                                      device=None if dev is None else (dev if isinstance(dev, str) else f"cuda:{int(dev)}"),
+                                      fp16=bool(getattr(rcfg, "rerank_fp16", False)))
             rerank_top_n = int(getattr(rcfg, "rerank_top_n", min(40, max(10, top_k * 4))))
             beta = float(getattr(rcfg, "rerank_beta", 0.35))
             cand = fused[:rerank_top_n]

@@ -94,6 +94,7 @@ class CrossEncoderReranker:
     device: Optional[str] = None
     max_length: int = 512
     batch_size: int = 32
+    fp16: bool = False  # sentence_transformers.CrossEncoder.predict runs fp32; half precision is an explicit knob
 
     def __post_init__(self):
         if not os.path.isdir(self.model_name):
@@ -106,7 +107,7 @@ class CrossEncoderReranker:
         self._device = torch.device(self.device or ("cuda" if torch.cuda.is_available() else "cpu"))
         self._tok = AutoTokenizer.from_pretrained(self.model_name, local_files_only=True)
         model = AutoModelForSequenceClassification.from_pretrained(self.model_name, local_files_only=True)
-        self._model = (model.half() if self._device.type == "cuda" else model).to(self._device).eval()
+        self._model = (model.half() if (self.fp16 and self._device.type == "cuda") else model).to(self._device).eval()
 
     def score_batch(self, query: str, docs: List[str]) -> List[float]:
         torch, out = self._torch, []
@@ -238,21 +239,27 @@ class AsyncCachedLLMReranker(AsyncLLMReranker):
 class RerankerFactory:
     """An LLM judge when an llm is given and top_k <= llm_threshold, otherwise the
     cross-encoder, loaded once per model name for the whole process (rerankers.py:281-312)."""
-    _cross_cache: Dict[str, Any] = {}
+    _cross_cache: Dict[Any, Any] = {}
 
     def __init__(self, llm: Any = None, cross_model: str = "BAAI/bge-reranker-base", llm_threshold: int = 30,
-                 use_cache: bool = True):
+                 use_cache: bool = True, device: Optional[str] = None, fp16: bool = False):
         self.llm, self.cross_model = llm, cross_model
         self.llm_threshold, self.use_cache = llm_threshold, use_cache
+        self.device, self.fp16 = device, fp16
         self._cache: Dict[Tuple[int, int], float] = {}
 
     def create(self, top_k: int):
         if self.llm is not None and top_k <= self.llm_threshold:
             return CachedLLMReranker(llm=self.llm, cache=self._cache) if self.use_cache else LLMReranker(llm=self.llm)
         shared = type(self)._cross_cache
-        if self.cross_model not in shared:
-            shared[self.cross_model] = CrossEncoderReranker(model_name=self.cross_model)
-        return shared[self.cross_model]
+        key = (self.cross_model, self.device, self.fp16)
+        if key not in shared:
+            if self.cross_model == "hashing":  # explicit choice of the deterministic stand-in (encoders.py)
+                from ..encoders import HashingCrossScorer
+                shared[key] = HashingCrossScorer()
+            else:
+                shared[key] = CrossEncoderReranker(model_name=self.cross_model, device=self.device, fp16=self.fp16)
+        return shared[key]
 
 
 # ------------------------------------------------------------------ entry point

@@ -63,7 +63,7 @@ class VectorStore:
         self.device = f"cuda:{self.device_index}"
         self.model = encoders.get_embedder(str(rcfg.embedding_model),
                                            backend=str(getattr(rcfg, "encoder_backend", "auto")),
-                                           dim=int(getattr(rcfg, "embedding_dim", 768)))
+                                           dim=int(getattr(rcfg, "embedding_dim", 768)), device=self.device)
         self.index: FlatIPIndex | None = None
         self.chunks: List[LawChunk] = []
         self._index_mtime: float | None = None
