@@ -16,6 +16,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -98,6 +99,64 @@ __device__ __forceinline__ int bm25_argmax_rounds(const double* sc, int m, int k
   return got;
 }
 
+// The same ranking by a cheaper route, taken first: candidates are chosen on fp32 IMAGES of the
+// fp64 scores with the register selector of topk.hpp (64-bit integer keys at the full vector
+// rate instead of k rounds of half-rate fp64 compares and a scalar mask search per register),
+// then the exact fp64 order is CHECKED, not assumed.  Rounding is monotone (s1 > s2 => f(s1) >=
+// f(s2)), so every document whose image is below the image of the k-th best cannot be in the
+// top k; all documents whose image reaches the cut take part (the threshold test looks at the
+// score half of the key only).  After the survivors are sorted by (image desc, doc asc) the
+// order can differ from the exact (score desc, doc asc) order only inside a run of equal
+// images: if any neighbouring pair up to the cut has equal images but different fp64 scores the
+// function gives up (-1) and the caller runs the exact arg-max rounds.  More than 64 survivors
+// (mass ties at the cut: e.g. every document at score 0) -> -1 as well.
+template <int NV>
+__device__ __forceinline__ int bm25_select_f32(const double* sc, int m, int k, long lo, int lane, C32* scratch,
+                                               C64* out) {
+  C32 keys[NV];
+  C32 lbest = C32::pad();
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int i = lane + 64 * v;
+    keys[v] = (i < m) ? C32::make((float)sc[i], (u32)i) : C32::pad();  // ord32: -0.0 -> +0.0, NaN lowest
+    if (better(keys[v], lbest)) lbest = keys[v];
+  }
+  const C32 sorted_best = wave_sort64_desc(lbest, lane);
+  const C32 T = wave_bcast(sorted_best, k - 1 < 63 ? k - 1 : 63);  // k-th lane best: a lower bound of the k-th best
+  const u32 th = (u32)(T.c >> 32);  // pad -> 0: every document passes
+  int cnt = 0;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const bool pass = !keys[v].is_pad() && (u32)(keys[v].c >> 32) >= th;
+    const u64 mk = __ballot(pass);
+    const int tot = __popcll(mk);
+    if (cnt + tot > 64) return -1;
+    const u64 lt = (lane == 0) ? 0ull : (mk & (~0ull >> (64 - lane)));
+    if (pass) scratch[cnt + __popcll(lt)] = keys[v];
+    cnt += tot;
+  }
+  wave_lds_fence();
+  C32 c = (lane < cnt) ? scratch[lane] : C32::pad();
+  if (cnt <= 16)
+    c = wave_sortN_desc<C32, 16>(c, lane);
+  else if (cnt <= 32)
+    c = wave_sortN_desc<C32, 32>(c, lane);
+  else
+    c = wave_sortN_desc<C32, 64>(c, lane);
+  // exact scores of the survivors, and the check of every neighbouring pair up to the cut
+  const int doc = (lane < cnt) ? (int)c.id() : 0;
+  double x = sc[doc] + 0.0;
+  x = (x != x) ? -DBL_MAX : x;
+  const u32 img = (u32)(c.c >> 32);
+  const u32 img_n = (u32)__shfl_down((int)img, 1);
+  const double x_n = __shfl_down(x, 1);
+  const bool undecided = lane < k && lane + 1 < cnt && img == img_n && x != x_n;
+  if (__ballot(undecided)) return -1;
+  const int got = cnt < k ? cnt : k;
+  if (lane < got) out[lane] = C64::make(x, lo + doc);
+  return got;
+}
+
 // grid: (x = doc slabs, y = queries).  LDS: double sc[slab] + C64 lists[WAVES][cap] + int cnts[4] + token table [64]
 // The host launches WAVES = 1 only (one wave per (query, slab): no block barriers, no list
 // combine) — the 4-wave form the template still allows lost at every corpus size measured
@@ -107,7 +166,7 @@ template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void bm25_score_topk_kernel(
     const long long* __restrict__ term_ptr, const int* __restrict__ post_doc, const double* __restrict__ post_w,
     const double* __restrict__ idf, long n_terms, long n_docs, const int* __restrict__ q_terms,
-    const long long* __restrict__ q_ptr, int nq, int k, int cap, int slab,
+    const long long* __restrict__ q_ptr, int nq, int k, int cap, int slab, int use_select,
     double* __restrict__ scores_out /* nullable [nq, n_docs] */, C64* __restrict__ part /* nullable [nslabs][nq][k] */,
     double* __restrict__ fin_scores /* nullable [nq,k]: single slab */, long long* __restrict__ fin_ids) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -241,8 +300,25 @@ __global__ __launch_bounds__(WAVES * 64) void bm25_score_topk_kernel(
   bool done = false;
   if (WAVES == 1 && bm_use_argmax(k, slab)) {
     const int nv = (m + 63) >> 6;
-    int got;
-    if (nv <= 4)
+    int got = -1;
+    if (k <= 64 && use_select) {  // fp32-image candidates + exact check; -1 = undecided, fall through to the exact rounds
+      C32* scratch = reinterpret_cast<C32*>(tk.buf + k);
+      if (nv <= 4)
+        got = bm25_select_f32<4>(sc, m, k, lo, lane, scratch, tk.buf);
+      else if (nv <= 8)
+        got = bm25_select_f32<8>(sc, m, k, lo, lane, scratch, tk.buf);
+      else if (nv <= 10)
+        got = bm25_select_f32<10>(sc, m, k, lo, lane, scratch, tk.buf);
+      else if (nv <= 16)
+        got = bm25_select_f32<16>(sc, m, k, lo, lane, scratch, tk.buf);
+      else if (nv <= 20)
+        got = bm25_select_f32<20>(sc, m, k, lo, lane, scratch, tk.buf);
+      else
+        got = bm25_select_f32<32>(sc, m, k, lo, lane, scratch, tk.buf);
+      wave_lds_fence();
+    }
+    if (got >= 0) {
+    } else if (nv <= 4)
       got = bm25_argmax_rounds<4>(sc, m, k, lo, lane, tk.buf);
     else if (nv <= 8)
       got = bm25_argmax_rounds<8>(sc, m, k, lo, lane, tk.buf);
@@ -366,10 +442,17 @@ void bm_plan(int64_t n_docs, int nq, int k, BmPlan* p) {
   if (!argmax) balanced(kSlabMax);
   p->waves = 1;
   p->cap_merge = topk_cap(k);
-  p->cap = argmax ? (k <= 16 ? 16 : kBmArgmaxK) : p->cap_merge;
+  // arg-max path: k result slots + 32 slots (= 64 C32 entries) of scratch for bm25_select_f32
+  p->cap = argmax ? ((k <= 16 ? 16 : kBmArgmaxK) + 32) : p->cap_merge;
   p->lds = (size_t)p->slab * sizeof(double) + (size_t)p->waves * p->cap * sizeof(C64) + 4 * sizeof(int) +
            64 * (2 * sizeof(long) + sizeof(double)) + 8;
   p->part_bytes = (size_t)p->nslabs * nq * k * sizeof(C64);
+}
+
+// AMDR_BM25_SELECT=0 pins the exact arg-max rounds (A/B and tests of the fallback path)
+static bool bm_select_enabled() {
+  const char* e = getenv("AMDR_BM25_SELECT");
+  return !(e && e[0] == '0');
 }
 
 int bm_run(amdr_bm25* h, int ws, const int* q_terms_dev, const long long* q_ptr_dev, int nq, int k, double* scores_dev,
@@ -391,7 +474,7 @@ int bm_run(amdr_bm25* h, int ws, const int* q_terms_dev, const long long* q_ptr_
   }
   hipLaunchKernelGGL(bm25_score_topk_kernel<1>, dim3(p.nslabs, nq), dim3(64), p.lds, st, h->term_ptr, h->post_doc,
                      h->post_w, h->idf, (long)h->n_terms, (long)h->n_docs, q_terms_dev, q_ptr_dev, nq, k, p.cap,
-                     p.slab, full_dev, part, fs, fi);
+                     p.slab, bm_select_enabled() ? 1 : 0, full_dev, part, fs, fi);
   AMDR_HIP(hipGetLastError());
   if (scores_dev && !direct) {
     size_t lds = (size_t)kBmWaves * p.cap_merge * sizeof(C64) + kBmWaves * sizeof(int);

@@ -280,6 +280,48 @@ def test_bm25_bit_exact(nat, n_docs, vocab, max_len, k):
         assert np.all(i[qn, kk:] == -1)
 
 
+def test_bm25_fp32_image_ties_fall_back_to_exact_order(nat):
+    """The fast ranking picks candidates on fp32 images of the fp64 scores and must give up
+    whenever two neighbours share an image but differ in fp64 (csrc/bm25.hip bm25_select_f32):
+    hand-made idf values 1e-12 apart put the HIGHER score on the HIGHER doc id, so an order taken
+    from the images alone (ties -> lower id) would be wrong."""
+    n, V = 300, 40
+    rng = np.random.default_rng(42)
+    term_of_doc = rng.integers(0, V, size=n)           # every document holds exactly one term once
+    order = np.argsort(term_of_doc, kind="stable")
+    term_ptr = np.concatenate([[0], np.cumsum(np.bincount(term_of_doc, minlength=V))]).astype(np.int64)
+    post_doc = order.astype(np.int32)
+    post_tf = np.ones(n, dtype=np.int32)
+    doc_len = np.full(n, 7, dtype=np.int32)
+    idf = 1.0 + 1e-12 * np.arange(V, dtype=np.float64)  # all 40 images equal in fp32
+    assert len(set(np.float32(idf).tolist())) == 1
+    gi = nat.BM25Index(term_ptr, post_doc, post_tf, idf, doc_len, 7.0, 1.5, 0.75)
+    queries = [list(range(V)), [5, 17, 39], [39], [0, 0, 3]]
+    full = gi.get_scores(queries)
+    for k in (10, 64, 80):
+        s, i = gi.search(queries, k)
+        for qn in range(len(queries)):
+            exp = sorted(range(n), key=lambda d: full[qn][d], reverse=True)[:k]  # stable: ties -> lower id
+            assert i[qn].tolist() == exp
+            assert s[qn].tolist() == [full[qn][d] for d in exp]
+
+
+def test_bm25_select_and_exact_rounds_agree(nat, monkeypatch):
+    """AMDR_BM25_SELECT=0 pins the exact arg-max rounds: both rankings give identical bits on a
+    Zipf corpus with queries that leave most documents at score 0 (mass ties at the cut)."""
+    rng = np.random.default_rng(7)
+    docs, words = toy_corpus(rng, 591, 3000, 300)
+    ob, csr, gi = bm25_pair(nat, docs)
+    queries = [[int(t) for t in rng.integers(0, 3000, size=int(rng.integers(0, 9)))] for _ in range(200)]
+    queries += [[], [-1, -1], [2999]]
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("AMDR_BM25_SELECT", flag)
+        out[flag] = [gi.search(queries, k) for k in (1, 10, 16, 40)]
+    for a, b in zip(out["1"], out["0"]):
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
+
+
 def test_bm25_toy_golden(nat):
     g = load_golden("bm25_toy.json")
     from oracle import bm25 as OB
