@@ -23,6 +23,7 @@ from __future__ import annotations
 
 import logging
 import math
+import threading
 import time
 import traceback
 from dataclasses import dataclass
@@ -296,20 +297,31 @@ class HybridRetriever:
         if eff_top_k < top_k:
             eff_top_k = top_k
 
-        t0 = time.time()
-        dense_hits = self.search_dense(question, eff_top_k)
-        t1 = time.time()
-        bm25_hits = self.search_bm25(question, eff_top_k)
-        t2 = time.time()
-        colbert_hits = self.search_colbert(question, eff_top_k)
-        t3 = time.time()
-
         min_final = float(getattr(rcfg, "min_final_score", 0.0))
-        all_fused, nat = self._fuse(dense_hits=dense_hits, bm25_hits=bm25_hits, colbert_hits=colbert_hits,
-                                    _min_final=min_final, _return_native=True)
-        kept = int(nat[3][0]) if nat is not None else 0
-        fused = all_fused[:kept]  # hits with score >= min_final_score (sorted, so a prefix)
-        t4 = time.time()
+        native = self._native_channels(eff_top_k)
+        if native is not None:
+            # device-resident form: query vectors up, dense / BM25 / MaxSim top-k -> fuse -> filter on ONE
+            # stream, ONE synchronise, one set of copies back (the kernels and results are those of the
+            # per-channel path below; tests pin the two against each other)
+            t0 = time.time()
+            outs, stamps = self._batch_native([question], eff_top_k, native, min_final)
+            fused = outs[0]
+            t1, t2, t3 = stamps
+            t4 = time.time()
+        else:
+            t0 = time.time()
+            dense_hits = self.search_dense(question, eff_top_k)
+            t1 = time.time()
+            bm25_hits = self.search_bm25(question, eff_top_k)
+            t2 = time.time()
+            colbert_hits = self.search_colbert(question, eff_top_k)
+            t3 = time.time()
+
+            all_fused, nat = self._fuse(dense_hits=dense_hits, bm25_hits=bm25_hits, colbert_hits=colbert_hits,
+                                        _min_final=min_final, _return_native=True)
+            kept = int(nat[3][0]) if nat is not None else 0
+            fused = all_fused[:kept]  # hits with score >= min_final_score (sorted, so a prefix)
+            t4 = time.time()
 
         t_graph = None
         if getattr(rcfg, "enable_graph", False) and _is_graph_mode(getattr(decision, "mode", None)):
@@ -376,50 +388,124 @@ class HybridRetriever:
             out.append(h)
         return out
 
-    # ----------------------------------------------------------- batch form
-    def search_batch(self, questions: Sequence[str], top_k: int = 10) -> List[List[RetrievalHit]]:
-        """Throughput form of `search` without rerank: one kernel pipeline for the
-        whole batch (dense + BM25 (+ ColBERT) -> fuse -> filter), results built once."""
+    # ------------------------------------------------- device-resident stage
+    def _native_channels(self, eff: int):
+        """(dense store, bm25 retriever, colbert retriever | None) when every channel is this
+        package's own retriever over the SAME chunk list, so that one row number means one chunk in
+        all of them and the whole stage can stay in HBM; None -> the per-channel path (duck-typed
+        retrievers, indexes built over different chunk lists, depth beyond the kernels' limit,
+        AMDR_SEARCH_NATIVE=0)."""
+        import os
+        if os.environ.get("AMDR_SEARCH_NATIVE") == "0" or eff > _native.MAX_K:
+            return None
+        if not isinstance(self.dense, DenseRetriever) or not isinstance(self.bm25, BM25Retriever):
+            return None
+        if self.colbert is not None and not isinstance(self.colbert, ColBERTRetriever):
+            return None
+        try:
+            self.dense.store.load()
+            self.bm25.load()
+            col = self.colbert if (self.colbert is not None and self.colbert.enabled) else None
+            if col is not None:
+                col._load_meta_and_collection()
+        except Exception:  # noqa: BLE001 - the per-channel path raises the reference's own errors
+            return None
+        store = self.dense.store
+        key = (id(store.index), id(self.bm25.bm25), id(col._searcher) if col is not None else None,
+               id(col._pid2chunk) if col is not None else None)
+        cached = self.__dict__.get("_native_key")
+        if cached != key:
+            a, b = store.chunks, self.bm25.chunks
+            same = len(a) == len(b) and all(x.id == y.id for x, y in zip(a, b))
+            if same and col is not None:
+                same = len(col._pid2chunk) == len(a) and all(
+                    (col._pid2chunk.get(i) is not None and col._pid2chunk[i].id == c.id) for i, c in enumerate(a))
+            self.__dict__["_native_key"] = key
+            self.__dict__["_native_ok"] = bool(same) and getattr(store.index, "native", None) is not None
+            self.__dict__["_native_engine"] = None
+        if not self.__dict__.get("_native_ok"):
+            return None
+        return store, self.bm25, col
+
+    def _batch_native(self, questions: Sequence[str], eff: int, native, min_final: float):
+        """Embed / tokenise on the host, then dense + BM25 (+ MaxSim) top-k -> fuse -> min_final
+        count for the whole batch on torch's current stream, one synchronise, results built once.
+        Returns ([fused hits with score >= min_final per question], (t_after_dense_prep, t_after_bm25_prep,
+        t_after_colbert_prep))."""
         import torch
-        from .. import text
         from .engine import HybridEngine
 
-        rcfg = self.cfg.retrieval
-        top_k = max(1, int(top_k))
-        eff = int(getattr(rcfg, "top_k", top_k * 8) or (top_k * 8))
-        eff = min(max(eff, top_k), _native.MAX_K)
-        self.dense.store.load()
-        self.bm25.load()
-        if len(self.dense.store.chunks) != len(self.bm25.chunks) or any(
-                a.id != b.id for a, b in zip(self.dense.store.chunks[:64], self.bm25.chunks[:64])):
-            raise RuntimeError("search_batch requires the dense and BM25 indexes to be built over the same chunk list")
-        dev = int(getattr(rcfg, "device", 0))
+        store, bm, col = native
+        if col is not None and any(not (q or "").strip() for q in questions):
+            # an empty question switches the ColBERT channel off for that question (colbert_retriever.py:147-149)
+            blank = [i for i, q in enumerate(questions) if not (q or "").strip()]
+            rest = [i for i in range(len(questions)) if i not in set(blank)]
+            out = [None] * len(questions)
+            stamps = (time.time(),) * 3
+            for idxs, nat in ((blank, (store, bm, None)), (rest, native)):
+                if idxs:
+                    part, stamps = self._batch_native([questions[i] for i in idxs], eff, nat, min_final)
+                    for i, h in zip(idxs, part):
+                        out[i] = h
+            return out, stamps
+        dev = int(getattr(self.cfg.retrieval, "device", 0))
         tdev = torch.device("cuda", dev)
-        eng = HybridEngine(self.dense.store.index.native, self.bm25.bm25.gpu(dev),
-                           self.colbert._searcher if self.colbert is not None else None, device=dev)
-        Q = self.dense.store._embed(list(questions), is_query=True)
+        Q = np.ascontiguousarray(store._embed(list(questions), is_query=True), dtype=np.float32)
+        t1 = time.time()
         tids, exact = [], []
         for q in questions:
-            tids.append(self.bm25.bm25.term_ids(self.bm25.tokenize_query(q)))
-            exact.append(self.bm25.zh_exact)
+            tids.append(bm.bm25.term_ids(bm.tokenize_query(q)))
+            exact.append(bm.zh_exact)
         qt, qp = _native.BM25Index.pack_queries(tids)
-        q_tok = None
-        if self.colbert is not None:
-            q_tok = torch.from_numpy(np.stack([self.colbert._encoder.encode_query(q.strip()) for q in questions])
-                                     .astype(np.float32)).to(tdev)
+        t2 = time.time()
+        q_tok_h = None
+        if col is not None:
+            try:
+                q_tok_h = np.stack([np.asarray(col._encoder.encode_query((q or "").strip()), dtype=np.float32)
+                                    for q in questions])
+            except Exception:  # noqa: BLE001 - the reference swallows ColBERT channel errors (:244-245)
+                col, q_tok_h = None, None
+        t3 = time.time()
         kn = self._knobs()
-        res = eng.search_batch(self._params(kn, float(getattr(rcfg, "min_final_score", 0.0))), eff,
-                               q_emb=torch.from_numpy(np.ascontiguousarray(Q)).to(tdev),
-                               q_terms=torch.from_numpy(qt).to(tdev), q_ptr=torch.from_numpy(qp).to(tdev), q_tok=q_tok)
-        torch.cuda.synchronize(tdev)
-        ids, vals, mask, cnt = (res.ids.cpu().numpy(), res.vals.cpu().numpy(), res.mask.cpu().numpy(),
-                                res.count.cpu().numpy())
-        chunks = self.dense.store.chunks
+        lock = self.__dict__.setdefault("_native_lock", threading.Lock())
+        with lock:  # one batch at a time through the handles' "_device" workspace (include/amdretrieval.h)
+            engines = self.__dict__.get("_native_engine") or {}
+            eng = engines.get(col is not None)
+            if eng is None:
+                eng = HybridEngine(store.index.native, bm.bm25.gpu(dev), col._searcher if col is not None else None,
+                                   device=dev)
+                engines[col is not None] = eng
+                self.__dict__["_native_engine"] = engines
+            res = eng.search_batch(self._params(kn, min_final), eff,
+                                   q_emb=torch.from_numpy(Q).to(tdev, non_blocking=True),
+                                   q_terms=torch.from_numpy(qt).to(tdev, non_blocking=True),
+                                   q_ptr=torch.from_numpy(qp).to(tdev, non_blocking=True),
+                                   q_tok=torch.from_numpy(q_tok_h).to(tdev, non_blocking=True) if q_tok_h is not None else None)
+            # ONE synchronise: the D2H copies below run on the same stream and block until the data is there
+            ids, vals, mask, cnt = (res.ids.cpu().numpy(), res.vals.cpu().numpy(), res.mask.cpu().numpy(),
+                                    res.count.cpu().numpy())
+        chunks = store.chunks
         out = []
         for qi in range(len(questions)):
+            # only the hits that survive min_final_score are ever used (hybrid_retriever.py:309-310)
             hits = self._hits_from_native(ids[qi], vals[qi], mask[qi], int(cnt[qi]), kn, chunks)
             if not exact[qi]:
                 for h in hits:
                     h.score_breakdown["zh_exact"] = False
-            out.append(_dedup_keep_best(hits)[:top_k])
-        return out
+            out.append(hits)
+        return out, (t1, t2, t3)
+
+    # ----------------------------------------------------------- batch form
+    def search_batch(self, questions: Sequence[str], top_k: int = 10) -> List[List[RetrievalHit]]:
+        """Throughput form of `search` without rerank: one kernel pipeline for the
+        whole batch (dense + BM25 (+ ColBERT) -> fuse -> filter), results built once."""
+        rcfg = self.cfg.retrieval
+        top_k = max(1, int(top_k))
+        eff = int(getattr(rcfg, "top_k", top_k * 8) or (top_k * 8))
+        eff = min(max(eff, top_k), _native.MAX_K)
+        native = self._native_channels(eff)
+        if native is None:
+            raise RuntimeError("search_batch requires this package's own dense / BM25 (/ ColBERT) retrievers built "
+                               "over the same chunk list")
+        outs, _ = self._batch_native(list(questions), eff, native, float(getattr(rcfg, "min_final_score", 0.0)))
+        return [_dedup_keep_best(hits)[:top_k] for hits in outs]

@@ -243,6 +243,66 @@ def test_search_batch_equals_single_queries(ucc_index):
                 assert abs(gb["channel_contrib"][ch] - eb["channel_contrib"][ch]) <= 2e-5
 
 
+def test_search_native_stage_equals_per_channel_path(ucc_index, monkeypatch):
+    """search() keeps the whole retrieval stage in HBM (one stream, one synchronise) when every
+    channel is the package's own retriever; AMDR_SEARCH_NATIVE=0 pins the per-channel path of the
+    reference's structure.  Same kernels, same inputs: identical hits, scores and breakdowns —
+    including the strings handed to the cross-encoder."""
+    from legal_rag_amd.retrieval.hybrid_retriever import HybridRetriever
+    cfg, _ = ucc_index
+    cfg2 = copy.deepcopy(cfg)
+    cfg2.retrieval.rerank_ce_model = "hashing"  # explicit stand-in cross-encoder (rerankers.RerankerFactory)
+    r = HybridRetriever(cfg2)
+    assert r._native_channels(10) is not None
+    for top_k in (3, 10, 25):
+        for q in QUESTIONS + ["", "   ", "zzzz qqqq"]:
+            monkeypatch.setenv("AMDR_SEARCH_NATIVE", "0")
+            exp = [dump(h) for h in r.search(q, top_k=top_k)]
+            monkeypatch.delenv("AMDR_SEARCH_NATIVE")
+            got = [dump(h) for h in r.search(q, top_k=top_k)]
+            assert got == exp, (q, top_k)
+
+
+def test_search_and_search_batch_from_two_threads(ucc_index):
+    """Service threads in search() while another thread drives search_batch() on the same
+    singletons (VectorStore / BM25 / MaxSim handles): every result equals the single-threaded one."""
+    import threading
+    from legal_rag_amd.retrieval.hybrid_retriever import HybridRetriever
+    cfg, _ = ucc_index
+    cfg2 = copy.deepcopy(cfg)
+    cfg2.retrieval.enable_rerank = False
+    r = HybridRetriever(cfg2)
+    key = lambda hits: [(h.chunk.id, round(h.score, 4)) for h in hits]  # noqa: E731
+    single = {q: key(r.search(q, top_k=10)) for q in QUESTIONS}
+    batch_q = QUESTIONS * 7
+    batch_exp = [key(h) for h in r.search_batch(batch_q, top_k=10)]
+    errors = []
+
+    def singles():
+        for _ in range(40):
+            for q in QUESTIONS:
+                if key(r.search(q, top_k=10)) != single[q]:
+                    errors.append(("search", q))
+
+    def batches():
+        for _ in range(25):
+            if [key(h) for h in r.search_batch(batch_q, top_k=10)] != batch_exp:
+                errors.append(("search_batch",))
+
+    def host_api():  # the host-pointer entry points of the same handles, from yet another thread
+        for _ in range(40):
+            for q in QUESTIONS:
+                if key(r.search_dense(q, 10))[:3] != key(r.search_dense(q, 10))[:3]:
+                    errors.append(("dense", q))
+
+    ts = [threading.Thread(target=f) for f in (singles, singles, batches, host_api)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:5]
+
+
 def test_error_conventions(tmp_path):
     """Missing dense files -> FileNotFoundError; missing bm25 -> RuntimeError;
     missing colbert meta is swallowed at construction."""
