@@ -146,23 +146,31 @@ class TransformersBGE:
     def hidden_size(self) -> int:
         return int(self.model.config.hidden_size)
 
-    def encode(self, texts, batch_size: int = 64, max_length: int = 512) -> np.ndarray:
+    def encode_tensor(self, texts: Sequence[str], batch_size: int = 64, max_length: int = 512, is_query: bool = False):
+        """fp32 [n, hidden] tensor ON `self.device`, L2-normalised: the embedding goes from the
+        encoder to the dense kernel (amdr_dense_search_device) without a host hop."""
         torch = self.torch
-        single = isinstance(texts, str)
-        if single:
-            texts = [texts]
-        if len(texts) == 0:
-            return np.zeros((0, self.hidden_size), dtype=np.float32)
+        texts = [self.query_instruction + t for t in texts] if is_query else list(texts)
+        out = torch.zeros((len(texts), self.hidden_size), dtype=torch.float32, device=self.device)
+        if not texts:
+            return out
         order = np.argsort([-len(t) for t in texts])  # length-sorted batches, like FlagModel
-        out = np.zeros((len(texts), self.hidden_size), dtype=np.float32)
         with torch.inference_mode():
             for s in range(0, len(texts), batch_size):
                 idx = order[s:s + batch_size]
                 enc = self.tokenizer([texts[i] for i in idx], padding=True, truncation=True, max_length=max_length,
                                      return_tensors="pt").to(self.device)
                 h = self.model(**enc).last_hidden_state[:, 0]
-                h = torch.nn.functional.normalize(h.float(), dim=-1)
-                out[idx] = h.cpu().numpy()
+                out[torch.as_tensor(idx.copy(), device=self.device)] = torch.nn.functional.normalize(h.float(), dim=-1)
+        return out
+
+    def encode(self, texts, batch_size: int = 64, max_length: int = 512) -> np.ndarray:
+        single = isinstance(texts, str)
+        if single:
+            texts = [texts]
+        if len(texts) == 0:
+            return np.zeros((0, self.hidden_size), dtype=np.float32)
+        out = self.encode_tensor(texts, batch_size, max_length).cpu().numpy()
         return out[0] if single else out
 
     def encode_queries(self, texts, batch_size: int = 64, max_length: int = 512) -> np.ndarray:

@@ -450,7 +450,7 @@ class HybridRetriever:
             return out, stamps
         dev = int(getattr(self.cfg.retrieval, "device", 0))
         tdev = torch.device("cuda", dev)
-        Q = np.ascontiguousarray(store._embed(list(questions), is_query=True), dtype=np.float32)
+        q_emb = store.embed_device(list(questions), is_query=True)  # encoder output stays in HBM
         t1 = time.time()
         tids, exact = [], []
         for q in questions:
@@ -477,7 +477,7 @@ class HybridRetriever:
                 engines[col is not None] = eng
                 self.__dict__["_native_engine"] = engines
             res = eng.search_batch(self._params(kn, min_final), eff,
-                                   q_emb=torch.from_numpy(Q).to(tdev, non_blocking=True),
+                                   q_emb=q_emb,
                                    q_terms=torch.from_numpy(qt).to(tdev, non_blocking=True),
                                    q_ptr=torch.from_numpy(qp).to(tdev, non_blocking=True),
                                    q_tok=torch.from_numpy(q_tok_h).to(tdev, non_blocking=True) if q_tok_h is not None else None)

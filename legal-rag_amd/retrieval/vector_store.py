@@ -116,6 +116,18 @@ class VectorStore:
         embs = np.asarray(embs).astype("float32")
         return embs[0] if single else embs
 
+    def embed_device(self, texts: List[str], is_query: bool = False):
+        """Embeddings as a contiguous fp32 torch tensor on this store's device.  A PyTorch encoder
+        (TransformersBGE) hands its output over without leaving HBM; the hashing stand-in is
+        computed on the host and uploaded."""
+        import torch
+        tdev = torch.device("cuda", self.device_index)
+        if hasattr(self.model, "encode_tensor"):
+            t = self.model.encode_tensor(list(texts), batch_size=64, max_length=512, is_query=is_query)
+            return t.to(tdev).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(self._embed(list(texts), is_query=is_query), dtype=np.float32)) \
+            .to(tdev, non_blocking=True)
+
     def search(self, query: str, top_k: int) -> List[Tuple[LawChunk, float]]:
         self.load()
         q_vec = self._embed([query], is_query=True)
