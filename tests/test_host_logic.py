@@ -208,3 +208,55 @@ def test_llm_rerankers_and_factory_choice():
     assert got == [0.9, 0.25, 0.9]
     long_q = "x" * 1000
     assert len(r._call_llm(long_q, "alpha")) > 0
+
+
+# ---- /retrieve service contract (retrieval_api.py:51-77), vectors from the reference's own route ----
+def test_retrieve_response_matches_reference_route():
+    from types import SimpleNamespace
+    from legal_rag_amd import service
+    from legal_rag_amd.schemas import LawChunk, RetrievalHit
+    cases = load_golden("service_golden.json")["cases"]
+    assert len(cases) >= 10
+
+    def mk_hit(i, score, rank):
+        c = LawChunk(id=f"src.txt::{i}", law_name="Synthetic Code", article_no=f"§ {i}", article_id=str(i),
+                     text=f"text of provision {i}", lang="en", source="src.txt")
+        return RetrievalHit(chunk=c, score=score, rank=rank, source="retriever",
+                            score_breakdown={"channel": ["dense"], "dense_raw": score})
+
+    class Retriever:
+        def __init__(self):
+            self.calls = []
+
+        def search(self, question, top_k=10, decision=None):
+            self.calls.append({"question": question, "top_k": top_k, "mode": decision.mode})
+            return [mk_hit(i, 1.0 - 0.01 * i, i + 1) for i in range(min(top_k, 4))]
+
+    for case in cases:
+        if case.get("not_ready"):
+            with pytest.raises(service.ServiceError) as e:
+                service.retrieve_response(case["body"], None, None, None)
+            assert (e.value.status_code, e.value.detail) == (503, case["http_error"]["detail"])
+            continue
+        cfg = SimpleNamespace(retrieval=SimpleNamespace(top_k=case["cfg_top_k"]))
+        dec = SimpleNamespace(top_k_factor=case["top_k_factor"], mode=case["mode"])
+        dec.model_dump = lambda d=dec: case["response"]["decision"] if "response" in case else {}
+        router = SimpleNamespace(route=lambda q, d=dec: d)
+        r = Retriever()
+        if "http_error" in case:
+            with pytest.raises(service.ServiceError) as e:
+                service.retrieve_response(case["body"], r, router, cfg)
+            assert e.value.status_code == case["http_error"]["status_code"]
+            assert e.value.detail == case["http_error"]["detail"]
+            assert r.calls == []
+            continue
+        got = service.retrieve_response(case["body"], r, router, cfg)
+        assert got == case["response"], case["body"]
+        assert r.calls == case["search_calls"]
+    # the same clamp as RagPipeline.retrieve (rag_pipeline.py:249-251)
+    assert [service.effective_top_k(k, f) for k, f in ((10, 1.0), (1, 1.0), (25, 2.0), (5, 0.5), (9, 1.3))] == \
+        [10, 3, 30, 3, 11]
+    route = service.make_route(Retriever(), SimpleNamespace(route=lambda q: SimpleNamespace(top_k_factor=1.0)),
+                               SimpleNamespace(retrieval=SimpleNamespace(top_k=10)), http_exception=None)
+    with pytest.raises(service.ServiceError):
+        route({})
