@@ -17,6 +17,14 @@ the flat fp32 storage is used — the graph is what the exact scan replaces.
 FAISS's io format is restated from its published source (faiss/impl/index_write.cpp,
 faiss >= 1.7.4) [from memory — faiss is absent here; verify against a real file].
 
+colbert/<experiment>/indexes/<name>/ — this build writes its own exact fp32 token store
+(`amdr_tokens.npz`); a directory written by colbert-ai's Indexer (PLAID: centroids + 4-bit residual
+codes, colbert_builder.py:120-134) is READ and decompressed once into the same token store
+(`read_plaid_index`), so a reference-built ColBERT index is served unchanged.  colbert-ai's on-disk
+layout and residual codec are restated from its published source (colbert/indexing/codecs/
+residual.py, collection_indexer.py; colbert-ai >= 0.2.19) [from memory — colbert-ai is absent
+here; verify against a real index].
+
 bm25.pkl — written so that it unpickles as `rank_bm25.BM25Okapi` under the
 reference and read with a RESTRICTED unpickler (a pickle is code: only the
 handful of globals such a file legitimately contains are resolvable).
@@ -297,8 +305,83 @@ def write_token_store(dirpath: Path, D: np.ndarray, doc_ptr: np.ndarray) -> Path
 
 
 def read_token_store(dirpath: Path) -> Tuple[np.ndarray, np.ndarray]:
+    """(token embeddings fp32 [tokens, dim], doc_ptr i64 [n_docs + 1]) of a ColBERT index directory:
+    this build's own store if present, else a colbert-ai (PLAID) index decompressed on load."""
     p = Path(dirpath) / "amdr_tokens.npz"
-    if not p.exists():
-        raise RuntimeError(f"ColBERT token store not found: {p}. Run build_colbert_index() first.")
-    z = np.load(p)
-    return z["D"], z["doc_ptr"]
+    if p.exists():
+        z = np.load(p)
+        return z["D"], z["doc_ptr"]
+    if is_plaid_index(dirpath):
+        return read_plaid_index(dirpath)
+    raise RuntimeError(f"ColBERT token store not found: {p} (and {dirpath} is not a colbert-ai index directory). "
+                       f"Run build_colbert_index() first.")
+
+
+# ---------------------------------------------------------------------------
+# colbert-ai (PLAID) index directory  [upstream layout, from memory — verify]
+#   metadata.json            {"config": {"nbits", "dim", ...}, "num_chunks", "num_partitions", "num_embeddings", ...}
+#   centroids.pt             half [num_partitions, dim]
+#   buckets.pt               (bucket_cutoffs [2^nbits - 1], bucket_weights [2^nbits])
+#   avg_residual.pt          scalar (not needed to decompress)
+#   <c>.codes.pt             int32 [n_c]            centroid id per token embedding of chunk c
+#   <c>.residuals.pt         uint8 [n_c, dim * nbits / 8]   packed bucket indices
+#   <c>.metadata.json        {"passage_offset", "num_passages", "num_embeddings", "embedding_offset"}
+#   doclens.<c>.json         [tokens of each passage of chunk c]
+#   ivf.pid.pt               inverted lists centroid -> pids (candidate generation only: not needed,
+#                            this build scores every document exactly)
+# Codec (ResidualCodec.compress / binarize / decompress): per dimension the residual
+# (embedding - centroid) is bucketized into 2^nbits buckets; the index's bits are written LSB
+# FIRST and the flat bit string is packed with np.packbits (first bit -> MSB of the byte).
+# decompress = normalize(centroid + bucket_weights[index]).
+# ---------------------------------------------------------------------------
+def is_plaid_index(dirpath: Path) -> bool:
+    d = Path(dirpath)
+    return (d / "metadata.json").exists() and (d / "centroids.pt").exists() and (d / "0.codes.pt").exists()
+
+
+def _torch_load(path: Path):
+    import torch
+    return torch.load(str(path), map_location="cpu", weights_only=True)
+
+
+def plaid_unpack_indices(packed: np.ndarray, nbits: int, dim: int) -> np.ndarray:
+    """uint8 [n, dim * nbits / 8] -> bucket index per dimension, uint8 [n, dim]."""
+    n = packed.shape[0]
+    bits = np.unpackbits(np.ascontiguousarray(packed, dtype=np.uint8), axis=1)  # MSB first = write order
+    bits = bits.reshape(n, dim, nbits)                                            # bit j of the index at position j
+    weights = (1 << np.arange(nbits, dtype=np.uint8)).astype(np.uint8)            # LSB first
+    return (bits * weights).sum(axis=2).astype(np.uint8)
+
+
+def read_plaid_index(dirpath: Path) -> Tuple[np.ndarray, np.ndarray]:
+    d = Path(dirpath)
+    meta = json.loads((d / "metadata.json").read_text())
+    cfg = meta.get("config", {})
+    nbits = int(cfg.get("nbits", 4))
+    if nbits not in (1, 2, 4, 8):
+        raise RuntimeError(f"colbert index {d}: unsupported nbits={nbits}")
+    centroids = _torch_load(d / "centroids.pt").float().numpy()
+    dim = int(centroids.shape[1])
+    if int(cfg.get("dim", dim)) != dim:
+        raise RuntimeError(f"colbert index {d}: metadata dim {cfg.get('dim')} != centroid dim {dim}")
+    buckets = _torch_load(d / "buckets.pt")
+    weights = np.asarray(buckets[1].float().numpy(), dtype=np.float32)
+    if weights.shape[0] != (1 << nbits):
+        raise RuntimeError(f"colbert index {d}: {weights.shape[0]} bucket weights for nbits={nbits}")
+    parts, doclens = [], []
+    for c in range(int(meta["num_chunks"])):
+        codes = _torch_load(d / f"{c}.codes.pt").numpy().astype(np.int64)
+        packed = _torch_load(d / f"{c}.residuals.pt").numpy()
+        lens = json.loads((d / f"doclens.{c}.json").read_text())
+        if packed.shape[0] != codes.shape[0] or packed.shape[1] * 8 != dim * nbits or sum(lens) != codes.shape[0]:
+            raise RuntimeError(f"colbert index {d}: chunk {c} is inconsistent "
+                               f"(codes {codes.shape}, residuals {packed.shape}, doclens sum {sum(lens)})")
+        emb = centroids[codes] + weights[plaid_unpack_indices(packed, nbits, dim)]
+        emb /= np.maximum(np.linalg.norm(emb, axis=1, keepdims=True), 1e-12)
+        parts.append(emb.astype(np.float32))
+        doclens.extend(int(x) for x in lens)
+    D = np.concatenate(parts, axis=0) if parts else np.zeros((0, dim), dtype=np.float32)
+    if "num_embeddings" in meta and int(meta["num_embeddings"]) != D.shape[0]:
+        raise RuntimeError(f"colbert index {d}: {D.shape[0]} embeddings read, metadata says {meta['num_embeddings']}")
+    doc_ptr = np.concatenate([[0], np.cumsum(doclens)]).astype(np.int64)
+    return D, doc_ptr

@@ -391,3 +391,31 @@ def test_concurrent_searches_on_shared_singletons(ucc_index):
         got = list(ex.map(lambda q: (q, [(h.chunk.id, h.score) for h in r.search(q, top_k=10)]), work))
     for q, res in got:
         assert res == expect[q]
+
+
+def test_colbert_retriever_serves_a_plaid_layout_index(tmp_path):
+    """§8 a-12 / f-1: a ColBERT index directory in colbert-ai's on-disk layout (centroids + packed
+    4-bit residual codes) is decompressed at load and searched by the MaxSim kernel; scores equal
+    the oracle's MaxSim over the decompressed token embeddings."""
+    from test_artifacts import _write_plaid_fixture
+    from legal_rag_amd import artifacts
+    from legal_rag_amd.config import AppConfig
+    from legal_rag_amd.retrieval.builders.colbert_builder import build_colbert_index
+    from legal_rag_amd.retrieval.colbert_retriever import ColBERTRetriever
+    from legal_rag_amd.retrieval.corpus_loader import load_chunks_from_dir
+    from oracle import maxsim as OM
+    cfg = AppConfig.for_data_dir(str(tmp_path), "en")
+    cfg.retrieval.encoder_backend = "hashing"
+    chunks = load_chunks_from_dir(str(GOLDEN / "corpus"), "law_en.jsonl")[:40]
+    out_dir = build_colbert_index(cfg, chunks)                       # writes colbert_meta.jsonl + the fp32 store
+    D, doc_ptr = artifacts.read_token_store(out_dir)
+    (out_dir / "amdr_tokens.npz").unlink()                            # keep only what colbert-ai would have written
+    exp_tokens = _write_plaid_fixture(out_dir, D, np.diff(doc_ptr).tolist(), nbits=4, n_centroids=64, chunk_docs=16)
+    r = ColBERTRetriever(cfg)
+    q = "what warranty does a merchant give that goods are merchantable"
+    got = r.search(q, top_k=10)
+    assert len(got) == 10
+    qt = r._encoder.encode_query(q)[None]
+    es, ei = OM.maxsim_topk(qt, exp_tokens, doc_ptr, 10)
+    assert [c.id for c, _ in got] == [chunks[i].id for i in ei[0]]
+    assert np.allclose([s for _, s in got], es[0], atol=1e-4)

@@ -116,3 +116,75 @@ def test_token_store_roundtrip(tmp_path):
     assert np.array_equal(D, D2) and np.array_equal(ptr, ptr2)
     with pytest.raises(RuntimeError):
         artifacts.read_token_store(tmp_path / "nope")
+
+
+# ---- colbert-ai (PLAID) index directory: read + decompress (layout restated from memory, see artifacts.py) ----
+def _write_plaid_fixture(d, D, doclens, nbits=4, n_centroids=16, chunk_docs=3, seed=0):
+    """A small index in colbert-ai's on-disk layout, written with colbert-ai's own packing steps
+    (bucketize -> bits LSB first -> np.packbits) on torch tensors."""
+    import json
+    import torch
+    rng = np.random.default_rng(seed)
+    dim = D.shape[1]
+    centroids = rng.standard_normal((n_centroids, dim)).astype(np.float32)
+    centroids /= np.linalg.norm(centroids, axis=1, keepdims=True)
+    codes = np.argmax(D @ centroids.T, axis=1).astype(np.int32)
+    resid = D - centroids[codes]
+    q = np.quantile(resid, np.linspace(0, 1, (1 << nbits) + 1))
+    cutoffs = q[1:-1].astype(np.float32)
+    weights = np.array([(q[i] + q[i + 1]) / 2 for i in range(1 << nbits)], dtype=np.float32)
+    idx = torch.bucketize(torch.from_numpy(resid).float(), torch.from_numpy(cutoffs)).to(torch.uint8)
+    bits = (idx.unsqueeze(-1) >> torch.arange(0, nbits, dtype=torch.uint8)) & 1          # ResidualCodec.binarize
+    packed = np.packbits(np.asarray(bits.contiguous().flatten())).reshape(D.shape[0], dim // 8 * nbits)
+    d.mkdir(parents=True, exist_ok=True)
+    torch.save(torch.from_numpy(centroids).half(), d / "centroids.pt")
+    torch.save((torch.from_numpy(cutoffs), torch.from_numpy(weights)), d / "buckets.pt")
+    torch.save(torch.tensor(float(np.abs(resid).mean())), d / "avg_residual.pt")
+    ptr = np.concatenate([[0], np.cumsum(doclens)])
+    chunks = [list(range(i, min(i + chunk_docs, len(doclens)))) for i in range(0, len(doclens), chunk_docs)]
+    for c, docs in enumerate(chunks):
+        lo, hi = int(ptr[docs[0]]), int(ptr[docs[-1] + 1])
+        torch.save(torch.from_numpy(codes[lo:hi].copy()), d / f"{c}.codes.pt")
+        torch.save(torch.from_numpy(packed[lo:hi].copy()), d / f"{c}.residuals.pt")
+        (d / f"doclens.{c}.json").write_text(json.dumps([int(doclens[i]) for i in docs]))
+        (d / f"{c}.metadata.json").write_text(json.dumps({"passage_offset": docs[0], "num_passages": len(docs),
+                                                          "num_embeddings": hi - lo, "embedding_offset": lo}))
+    (d / "metadata.json").write_text(json.dumps({"config": {"nbits": nbits, "dim": dim}, "num_chunks": len(chunks),
+                                                 "num_partitions": n_centroids, "num_embeddings": int(D.shape[0]),
+                                                 "avg_doclen": float(np.mean(doclens))}))
+    # what decompression must give: normalize(half-rounded centroid + bucket weight)
+    exp = torch.from_numpy(centroids).half().float().numpy()[codes] + weights[idx.numpy()]
+    exp /= np.linalg.norm(exp, axis=1, keepdims=True)
+    return exp.astype(np.float32)
+
+
+@pytest.mark.parametrize("nbits", [4, 2, 1])
+def test_plaid_index_directory_is_read_and_decompressed(tmp_path, nbits):
+    from legal_rag_amd import artifacts
+    rng = np.random.default_rng(3)
+    doclens = [5, 1, 17, 220, 3, 8, 40]
+    D = rng.standard_normal((sum(doclens), 128)).astype(np.float32)
+    D /= np.linalg.norm(D, axis=1, keepdims=True)
+    d = artifacts.colbert_index_dir(str(tmp_path / "colbert"), "experiment", "law_en")
+    exp = _write_plaid_fixture(d, D, doclens, nbits=nbits)
+    assert artifacts.is_plaid_index(d)
+    got, doc_ptr = artifacts.read_token_store(d)            # no amdr_tokens.npz: the PLAID files are used
+    assert got.dtype == np.float32 and got.shape == D.shape
+    assert doc_ptr.tolist() == np.concatenate([[0], np.cumsum(doclens)]).tolist()
+    assert np.allclose(got, exp, atol=1e-6)
+    assert np.allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
+    if nbits == 4:
+        assert float(np.mean(np.sum(got * D, axis=1))) > 0.8  # the codec approximates the embeddings it stored
+    # a truncated chunk is refused, not mis-read
+    import json
+    (d / "doclens.0.json").write_text(json.dumps([5, 1]))
+    with pytest.raises(RuntimeError):
+        artifacts.read_plaid_index(d)
+
+
+def test_plaid_unpack_bit_order():
+    from legal_rag_amd import artifacts
+    # nbits = 4, two dims per byte: index 0b0001 (=1) then 0b0110 (=6), bits written LSB first, packed MSB first
+    # dim0 bits 1,0,0,0 ; dim1 bits 0,1,1,0  ->  byte 0b1000_0110 = 0x86
+    assert artifacts.plaid_unpack_indices(np.array([[0x86]], dtype=np.uint8), 4, 2).tolist() == [[1, 6]]
+    assert artifacts.plaid_unpack_indices(np.array([[0b10110000]], dtype=np.uint8), 2, 4).tolist() == [[1, 3, 0, 0]]
