@@ -355,6 +355,86 @@ __global__ __launch_bounds__(WAVES * 64) void scores_slab_topk_kernel(const floa
   }
 }
 
+// Two queries per wave (lanes 0-31 / 32-63), for rows of <= 1024 scores at k <= 32 when there is a
+// single slab — the serving corpora under a long batch.  grid.x = ceil(nq / 2); a wave whose
+// selector reports mass ties (-1) ranks its two rows one after the other with the staged selector.
+template <int V>
+__device__ __forceinline__ int select_row_pair(const float* __restrict__ S, long ldS, long n, int q, bool has_q, int k,
+                                               int lane, C32* scratch, C32& out) {
+  static_assert(V % 4 == 0, "four consecutive scores per 16-byte load");
+  C32 keys[V];
+  const float* row = S + (size_t)q * ldS;
+  const int j = lane & 31;
+  // 16-byte loads (a half-wave covers 512 B of its row per instruction): the kernel waits on memory
+  // for two thirds of its life, so fewer, wider requests in flight earlier is what shortens it.
+  // Rows are padded to ldS (a multiple of 32 floats), so a whole float4 below ldS is inside the row.
+  v4f blk[V / 4];
+#pragma unroll
+  for (int u = 0; u < V / 4; ++u) {
+    const long c0 = 128L * u + 4 * j;
+    const v4f z = {0.f, 0.f, 0.f, 0.f};
+    blk[u] = (has_q && c0 < ldS) ? *reinterpret_cast<const v4f*>(row + c0) : z;
+  }
+#pragma unroll
+  for (int u = 0; u < V / 4; ++u)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long r = 128L * u + 4 * j + e;
+      keys[4 * u + e] = (has_q && r < n) ? C32::make(blk[u][e], (u32)r) : C32::pad();
+    }
+  return wave_select_small_pair<C32, V>(keys, k, scratch, lane, out);
+}
+
+__global__ __launch_bounds__(64) void scores_pair_topk_kernel(const float* __restrict__ S, long ldS, long n, int nq,
+                                                              int k, int cap, float* __restrict__ fin_scores,
+                                                              long long* __restrict__ fin_ids) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  C32* buf = reinterpret_cast<C32*>(smem);  // cap entries (>= 128): staged-selector list; the pair selector uses 64
+  const int lane = threadIdx.x;
+  const int q = 2 * blockIdx.x + (lane >> 5);
+  const bool has_q = q < nq;
+  C32 out = C32::pad();
+  int got;
+  if (n <= 256)
+    got = select_row_pair<8>(S, ldS, n, q, has_q, k, lane, buf, out);
+  else if (n <= 512)
+    got = select_row_pair<16>(S, ldS, n, q, has_q, k, lane, buf, out);
+  else if (n <= 640)
+    got = select_row_pair<20>(S, ldS, n, q, has_q, k, lane, buf, out);
+  else
+    got = select_row_pair<32>(S, ldS, n, q, has_q, k, lane, buf, out);
+  if (got >= 0) {
+    const int j = lane & 31;
+    if (has_q && j < k) {
+      const bool v = j < got;
+      fin_scores[(size_t)q * k + j] = v ? out.score() : -FLT_MAX;
+      fin_ids[(size_t)q * k + j] = v ? out.id() : -1ll;
+    }
+    return;
+  }
+  // mass ties at the cut in one of the two rows: the general selector, one row after the other
+  for (int h = 0; h < 2; ++h) {
+    const int qq = 2 * blockIdx.x + h;
+    if (qq >= nq) break;
+    const float* row = S + (size_t)qq * ldS;
+    WaveTopK<C32> tk;
+    tk.init(buf, cap, k);
+    for (long base = 0; base < n; base += 64) {
+      const long r = base + lane;
+      const bool v = r < n;
+      tk.push_lanes(v ? C32::make(row[r], (u32)r) : C32::pad(), v, lane);
+    }
+    tk.finalize(lane);
+    for (int j = lane; j < k; j += 64) {
+      const bool v = j < tk.cnt;
+      const C32 c = v ? tk.buf[j] : C32::pad();
+      fin_scores[(size_t)qq * k + j] = v ? c.score() : -FLT_MAX;
+      fin_ids[(size_t)qq * k + j] = v ? c.id() : -1ll;
+    }
+    wave_lds_fence();
+  }
+}
+
 bool dense_mfma_supported(int d) { return d >= 64 && d <= 1024 && d % 64 == 0; }
 
 // Plan shared by reserve and launch.
@@ -480,6 +560,14 @@ int dense_mfma_launch_topk(const DenseMfmaPlan& p, const float* S, long n, int n
                            float* fin_scores, int64_t* fin_ids, hipStream_t st) {
   const int waves = p.rows_per_slab <= kSelectRowsMax ? 1 : kBW;
   size_t lds = (size_t)waves * p.cap * sizeof(C32) + waves * sizeof(int);
+  const char* pair_env = getenv("AMDR_TOPK_PAIR");  // "0" pins one query per wave (A/B, tests)
+  const bool pair_off = pair_env && pair_env[0] == '0';
+  if (fin_ids && p.slabs == 1 && n <= 1024 && k <= 32 && nq >= 2 && !pair_off) {
+    hipLaunchKernelGGL(scores_pair_topk_kernel, dim3((nq + 1) / 2), dim3(64), (size_t)p.cap * sizeof(C32), st, S, p.ld,
+                       n, nq, k, p.cap, fin_scores, (long long*)fin_ids);
+    AMDR_HIP(hipGetLastError());
+    return AMDR_OK;
+  }
   if (waves == 1)
     hipLaunchKernelGGL(scores_slab_topk_kernel<1>, dim3(p.slabs, nq), dim3(64), lds, st, S, p.ld, n, nq, k, p.cap,
                        p.rows_per_slab, (C32*)part, fin_scores, (long long*)fin_ids);

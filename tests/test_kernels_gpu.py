@@ -184,6 +184,29 @@ def test_dense_ties_lower_id_first(nat):
             assert s[b, 3 * t] == s[b, 3 * t + 1] == s[b, 3 * t + 2]
 
 
+def test_dense_pair_selector_mass_ties_and_agreement(nat, monkeypatch):
+    """Short rows under a batch are ranked two queries per wave (scores_pair_topk_kernel).  Mass ties
+    at the cut (every row identical: more than 32 survivors) must fall back to the general selector
+    and still return the lowest ids; and both forms must agree bit for bit on ordinary data."""
+    rng = np.random.default_rng(5)
+    row = unit_rows(rng, 1, 64)
+    X = np.repeat(row, 300, axis=0)
+    Q = unit_rows(rng, 7, 64)
+    idx = nat.DenseIndex(X)
+    s, i = idx.search(Q, 10)
+    assert all(i[b].tolist() == list(range(10)) for b in range(7))
+    idx.close()
+    X, Q = unit_rows(rng, 591, 768), unit_rows(rng, 333, 768)  # odd query count: the last wave holds one query
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("AMDR_TOPK_PAIR", flag)
+        idx = nat.DenseIndex(X)
+        out[flag] = [idx.search(Q, k) for k in (1, 10, 32)]
+        idx.close()
+    for a, b in zip(out["1"], out["0"]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
 def test_dense_adversarial_ascending_scores(nat):
     """Rows ordered so every new row beats all previous ones (worst case for the
     threshold/staging selector): result must still be exact."""
