@@ -239,6 +239,10 @@ void dense_panel_plan(long n, int d, int nq, DensePanelPlan* p) {
   p->nb = p->base + (p->rem ? 1 : 0);
   p->m_tiles = m_tiles;
   p->gm = 8;
+  if (const char* g = getenv("AMDR_PANEL_GM")) {
+    const int v = atoi(g);
+    if (v >= 1 && v <= 4096) p->gm = v;
+  }
   p->waves = kPanelWaves;
   p->lds = panel_lds(p->nb, kPanelWaves);
 }
