@@ -100,9 +100,8 @@ __device__ __forceinline__ int bm25_argmax_rounds(const double* sc, int m, int k
 }
 
 // The same ranking by a cheaper route, taken first: candidates are chosen on fp32 IMAGES of the
-// fp64 scores with the register selector of topk.hpp (64-bit integer keys at the full vector
-// rate instead of k rounds of half-rate fp64 compares and a scalar mask search per register),
-// then the exact fp64 order is CHECKED, not assumed.  Rounding is monotone (s1 > s2 => f(s1) >=
+// fp64 scores (32-bit integer keys at the full vector rate instead of k rounds of half-rate fp64
+// compares and a scalar mask search per register), then the exact fp64 order is CHECKED, not assumed.  Rounding is monotone (s1 > s2 => f(s1) >=
 // f(s2)), so every document whose image is below the image of the k-th best cannot be in the
 // top k; all documents whose image reaches the cut take part (the threshold test looks at the
 // score half of the key only).  After the survivors are sorted by (image desc, doc asc) the
@@ -113,26 +112,37 @@ __device__ __forceinline__ int bm25_argmax_rounds(const double* sc, int m, int k
 template <int NV>
 __device__ __forceinline__ int bm25_select_f32(const double* sc, int m, int k, long lo, int lane, C32* scratch,
                                                C64* out) {
-  C32 keys[NV];
-  C32 lbest = C32::pad();
+  // fp32 images as order-preserving 32-bit keys (ord32: -0.0 -> +0.0, NaN lowest; 0 = no document)
+  u32 img[NV];
+  u32 lb = 0u;
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     const int i = lane + 64 * v;
-    keys[v] = (i < m) ? C32::make((float)sc[i], (u32)i) : C32::pad();  // ord32: -0.0 -> +0.0, NaN lowest
-    if (better(keys[v], lbest)) lbest = keys[v];
+    img[v] = (i < m) ? ord32((float)sc[i]) : 0u;
+    lb = img[v] > lb ? img[v] : lb;
   }
-  const C32 sorted_best = wave_sort64_desc(lbest, lane);
-  const C32 T = wave_bcast(sorted_best, k - 1 < 63 ? k - 1 : 63);  // k-th lane best: a lower bound of the k-th best
-  const u32 th = (u32)(T.c >> 32);  // pad -> 0: every document passes
+  // The cut: the k-th largest of the 64 lane bests bounds the k-th best image from below.  It is
+  // found from the top bit down with one compare + ballot per bit — the candidate and the count live
+  // in scalar registers — instead of a 21-stage bitonic sort of 64-bit keys across the lanes (the
+  // sort was ~300 of the kernel's ~1 300 vector instructions per wave).
+  u32 T = 0u;
+#pragma unroll
+  for (int bit = 31; bit >= 0; --bit) {
+    const u32 cand = T | (1u << bit);
+    T = (__popcll(__ballot(lb >= cand)) >= k) ? cand : T;
+  }
   int cnt = 0;
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    const bool pass = !keys[v].is_pad() && (u32)(keys[v].c >> 32) >= th;
+    const bool pass = img[v] != 0u && img[v] >= T;
     const u64 mk = __ballot(pass);
     const int tot = __popcll(mk);
     if (cnt + tot > 64) return -1;
-    const u64 lt = (lane == 0) ? 0ull : (mk & (~0ull >> (64 - lane)));
-    if (pass) scratch[cnt + __popcll(lt)] = keys[v];
+    if (pass) {
+      C32 c;
+      c.c = ((u64)img[v] << 32) | (u64)(0xffffffffu - (u32)(lane + 64 * v));
+      scratch[cnt + (int)__builtin_amdgcn_mbcnt_hi((u32)(mk >> 32), __builtin_amdgcn_mbcnt_lo((u32)mk, 0u))] = c;
+    }
     cnt += tot;
   }
   wave_lds_fence();
@@ -147,10 +157,10 @@ __device__ __forceinline__ int bm25_select_f32(const double* sc, int m, int k, l
   const int doc = (lane < cnt) ? (int)c.id() : 0;
   double x = sc[doc] + 0.0;
   x = (x != x) ? -DBL_MAX : x;
-  const u32 img = (u32)(c.c >> 32);
-  const u32 img_n = (u32)__shfl_down((int)img, 1);
+  const u32 im = (u32)(c.c >> 32);
+  const u32 im_n = (u32)__shfl_down((int)im, 1);
   const double x_n = __shfl_down(x, 1);
-  const bool undecided = lane < k && lane + 1 < cnt && img == img_n && x != x_n;
+  const bool undecided = lane < k && lane + 1 < cnt && im == im_n && x != x_n;
   if (__ballot(undecided)) return -1;
   const int got = cnt < k ? cnt : k;
   if (lane < got) out[lane] = C64::make(x, lo + doc);
@@ -234,58 +244,52 @@ __global__ __launch_bounds__(WAVES * 64) void bm25_score_topk_kernel(
     // list bounds are wave-uniform (scalar registers): the loops and the short-list case branch
     // on scalars, a lane's offset is 32-bit, and out-of-range lanes read a clamped address and
     // are masked at the update — no divergent branches around the loads.
-    // The first chunk of token t+1 is requested before token t is applied (its address needs
-    // only the LDS table), so the per-token chain  load -> LDS update -> fence  overlaps one
-    // L2 round trip with the previous token's work.  Prefetch loads are unconditional (clamped
-    // index; the arrays carry one padding element) so the compiler can count them in s_waitcnt.
-    long ps_n = uniform_i64(tk_ps[0]);
-    int len_n = __builtin_amdgcn_readfirstlane((int)(tk_pe[0] - tk_ps[0]));
-    int d_n;
-    double x_n;
-    {
-      int jj = tid < len_n ? tid : len_n - 1;
-      jj = jj < 0 ? 0 : jj;
-      d_n = post_doc[ps_n + jj];
-      x_n = post_w[ps_n + jj];
-    }
+    // The posting lists of the kept tokens are walked as ONE sequence of 64-posting chunks, eight
+    // chunks (across token boundaries) requested before the first of them is applied: a wave then
+    // waits for an L2 round trip once per 512 postings instead of once or twice per token (the
+    // kernel spent 46 % of its wave cycles parked on s_waitcnt with the per-token prefetch).
+    // Chunks are applied in sequence order — token order, the accumulation order of rank_bm25 — and
+    // the LDS unit serves a wave's operations in order.
+    constexpr int kAhead = 8;
+    int t = 0, base = 0;
+    long ps = uniform_i64(tk_ps[0]);
+    int len = __builtin_amdgcn_readfirstlane((int)(tk_pe[0] - tk_ps[0]));
+    double w = tk_w[0];
 #if defined(AMDR_BM_ABL) && AMDR_BM_ABL == 2
-    for (int t = 0; t < 0; ++t) {
-#else
-    for (int t = 0; t < nt; ++t) {
+    t = nt;
 #endif
-      const long ps = ps_n;
-      const int len = len_n;
-      const int dfirst = d_n;
-      const double xfirst = x_n;
-      const double w = tk_w[t];
-      if (t + 1 < nt) {
-        ps_n = uniform_i64(tk_ps[t + 1]);
-        len_n = __builtin_amdgcn_readfirstlane((int)(tk_pe[t + 1] - tk_ps[t + 1]));
-        int jj = tid < len_n ? tid : len_n - 1;
+    while (t < nt) {
+      int dd[kAhead];
+      double ww[kAhead], wv[kAhead];
+      bool ok[kAhead];
+#pragma unroll
+      for (int u = 0; u < kAhead; ++u) {
+        const bool have = t < nt;  // wave-uniform
+        const int j = base + tid;
+        ok[u] = have && j < len;
+        int jj = ok[u] ? j : len - 1;
         jj = jj < 0 ? 0 : jj;
-        d_n = post_doc[ps_n + jj];
-        x_n = post_w[ps_n + jj];
-      }
-      if (tid < len) sc[dfirst - lo] += w * xfirst;
-      const int* __restrict__ pd = post_doc + ps;
-      const double* __restrict__ pw = post_w + ps;
-      for (int base = NT; base < len; base += 4 * NT) {  // lists longer than one chunk: four in flight
-        int dd[4];
-        double ww[4];
-        bool ok[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int j = base + u * NT + tid;
-          ok[u] = j < len;
-          const int jj = ok[u] ? j : len - 1;
-          dd[u] = pd[jj];
-          ww[u] = pw[jj];
+        dd[u] = post_doc[ps + jj];  // unconditional, clamped: countable in s_waitcnt
+        ww[u] = post_w[ps + jj];
+        wv[u] = w;
+        if (have) {
+          base += NT;
+          if (base >= len) {
+            ++t;
+            base = 0;
+            if (t < nt) {
+              ps = uniform_i64(tk_ps[t]);
+              len = __builtin_amdgcn_readfirstlane((int)(tk_pe[t] - tk_ps[t]));
+              w = tk_w[t];
+            }
+          }
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (ok[u]) sc[dd[u] - lo] += w * ww[u];
       }
-      block_sync<WAVES>();
+#pragma unroll
+      for (int u = 0; u < kAhead; ++u) {
+        if (ok[u]) sc[dd[u] - lo] += wv[u] * ww[u];
+        block_sync<WAVES>();
+      }
     }
   }
 
