@@ -121,10 +121,15 @@ class ColBERTRetriever:
         question = (query or "").strip()
         if not question:
             return []
-        depth = min(max(1, int(top_k)), _native.MAX_K)
+        depth = max(1, int(top_k))
         q_tokens = np.asarray(self._encoder.encode_query(question), dtype=np.float32)[None]
         try:
-            scores, pids = self._searcher.search(q_tokens, depth)
+            if depth <= _native.MAX_K:
+                scores, pids = self._searcher.search(q_tokens, depth)
+            else:  # beyond the kernels' depth: every document's MaxSim score, stable sort on the host
+                full = self._searcher.scores(q_tokens)[0]
+                order = np.argsort(-full, kind="stable")[:depth]
+                scores, pids = full[order][None], order.astype(np.int64)[None]
         except _native.NativeError as exc:
             if "out of memory" in str(exc).lower():
                 return []  # the reference answers GPU OOM with an empty channel (:153-172)

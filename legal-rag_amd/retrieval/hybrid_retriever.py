@@ -228,7 +228,10 @@ class HybridRetriever:
               _return_native: bool = False):
         kn = self._knobs()
         lists = {"dense": dense_hits, "bm25": bm25_hits, "colbert": colbert_hits}
-        for hs in lists.values():
+        for name, hs in lists.items():
+            if len(hs) > _native.MAX_K:  # never truncated silently: the fused list would change
+                raise ValueError(f"_fuse: {len(hs)} {name} hits exceed the fusion kernel's limit of {_native.MAX_K} per "
+                                 f"channel (cfg.retrieval.top_k / top_k too deep)")
             hs.sort(key=lambda h: float(h.score), reverse=True)
         # corpus-wide integer uid per chunk.id for this call; chunk lookup prefers
         # dense -> bm25 -> colbert (setdefault order, hybrid_retriever.py:426-429)
@@ -245,7 +248,7 @@ class HybridRetriever:
             # a repeated id inside one channel keeps its first (best-ranked) entry
             seen: Set[int] = set()
             ids, sc = [], []
-            for h in hs[: _native.MAX_K]:
+            for h in hs:
                 u = uid_of[h.chunk.id]
                 if u in seen:
                     continue
@@ -296,6 +299,11 @@ class HybridRetriever:
         eff_top_k = int(getattr(rcfg, "top_k", top_k * 8) or (top_k * 8))
         if eff_top_k < top_k:
             eff_top_k = top_k
+        if eff_top_k > _native.MAX_K:
+            # ONE clear error for every channel instead of a NativeError from one, a fallback in another and a
+            # silent clamp in the third (the per-channel searches themselves accept any depth)
+            raise ValueError(f"HybridRetriever.search: per-channel depth {eff_top_k} (max(cfg.retrieval.top_k, top_k)) "
+                             f"exceeds the fusion kernel's limit of {_native.MAX_K} hits per channel")
 
         min_final = float(getattr(rcfg, "min_final_score", 0.0))
         native = self._native_channels(eff_top_k)

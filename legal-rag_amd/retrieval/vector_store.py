@@ -36,8 +36,29 @@ class FlatIPIndex:
     def ntotal(self) -> int:
         return self._idx.ntotal
 
+    FULL_SCORES_MAX_ROWS = 1 << 20  # k beyond the kernels' depth limit: score every row, sort on the host
+
     def search(self, q: np.ndarray, k: int):
-        return self._idx.search(q, int(k))
+        """faiss `index.search` contract for any k (the reference accepts any cfg.retrieval.top_k):
+        up to AMDR_MAX_K the fused top-k kernels; deeper requests score every row on the device
+        (amdr_dense_score_rows) and take a stable descending sort on the host, like the BM25 channel."""
+        k = int(k)
+        if k <= _native.MAX_K:
+            return self._idx.search(q, k)
+        n = self.ntotal
+        if n > self.FULL_SCORES_MAX_ROWS:
+            raise ValueError(f"dense search depth {k} exceeds the kernels' limit of {_native.MAX_K} and the index has "
+                             f"{n} rows (full-score path is limited to {self.FULL_SCORES_MAX_ROWS})")
+        q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1, self.d)
+        rows = np.tile(np.arange(n, dtype=np.int64), (q.shape[0], 1))
+        full = self._idx.score_rows(q, rows) if n else np.zeros((q.shape[0], 0), dtype=np.float32)
+        scores = np.full((q.shape[0], k), -np.finfo(np.float32).max, dtype=np.float32)
+        ids = np.full((q.shape[0], k), -1, dtype=np.int64)
+        for b in range(q.shape[0]):
+            order = np.argsort(-full[b], kind="stable")[:k]
+            scores[b, :len(order)] = full[b, order]
+            ids[b, :len(order)] = order
+        return scores, ids
 
     def add(self, x: np.ndarray) -> None:
         self._idx.add(x)

@@ -419,3 +419,26 @@ def test_colbert_retriever_serves_a_plaid_layout_index(tmp_path):
     es, ei = OM.maxsim_topk(qt, exp_tokens, doc_ptr, 10)
     assert [c.id for c, _ in got] == [chunks[i].id for i in ei[0]]
     assert np.allclose([s for _, s in got], es[0], atol=1e-4)
+
+
+def test_depth_beyond_kernel_limit_is_handled_uniformly(ucc_index):
+    """AMDR_MAX_K = 256: every per-channel search accepts a deeper request (full scores on the device
+    + stable host sort), results continue the 256-deep ones; the fused search raises ONE clear error."""
+    from legal_rag_amd.retrieval.hybrid_retriever import HybridRetriever
+    cfg, chunks = ucc_index
+    cfg2 = copy.deepcopy(cfg)
+    cfg2.retrieval.enable_rerank = False
+    r = HybridRetriever(cfg2)
+    q = QUESTIONS[0]
+    n = len(chunks)
+    for fn in (r.search_dense, r.search_bm25, r.search_colbert):
+        deep, ref = fn(q, 300), fn(q, 256)
+        assert len(deep) == min(300, n) and len(ref) == min(256, n)
+        assert [h.chunk.id for h in deep[:len(ref)]] == [h.chunk.id for h in ref]
+        assert np.allclose([h.score for h in deep[:len(ref)]], [h.score for h in ref], atol=1e-5)
+        assert all(a.score >= b.score for a, b in zip(deep, deep[1:]))
+    with pytest.raises(ValueError, match="exceeds the fusion kernel"):
+        r.search(q, top_k=300)
+    big = [h for h in r.search_dense(q, 200)] * 2
+    with pytest.raises(ValueError, match="exceed the fusion kernel"):
+        r._fuse(dense_hits=big, bm25_hits=[], colbert_hits=[])

@@ -238,6 +238,24 @@ def test_dense_add_and_read_rows(nat):
     assert np.array_equal(i, ei)
 
 
+def test_handles_on_a_non_default_device(nat):
+    """The C ABI takes a device ordinal; kernels that need the > 64 KiB dynamic-LDS opt-in set the
+    attribute for the CURRENT device on every launch (a per-process "done" flag made a second device
+    fail).  Needs two visible GPUs: the driver's 8-GPU node runs it, a one-GPU box skips."""
+    if nat.device_count() < 2:
+        pytest.skip("one visible GPU")
+    rng = np.random.default_rng(12)
+    X, Q = unit_rows(rng, 591, 768), unit_rows(rng, 200, 768)
+    out = []
+    for dev in (0, 1):
+        idx = nat.DenseIndex(X, device=dev)
+        out.append(idx.search(Q, 10))        # long batch: panel kernel (56 KiB LDS)
+        out.append(idx.search(Q[:40], 10))   # short batch: 32x32 tile kernel (128 KiB LDS)
+        idx.close()
+    assert np.array_equal(out[0][1], out[2][1]) and np.array_equal(out[0][0], out[2][0])
+    assert np.array_equal(out[1][1], out[3][1]) and np.array_equal(out[1][0], out[3][0])
+
+
 def test_dense_errors(nat):
     with pytest.raises(nat.NativeError):
         nat.DenseIndex(np.zeros((4, 770), dtype=np.float32))  # dim not multiple of 4
