@@ -68,7 +68,6 @@ int check_device(int device);
 // ---- batched (32-query tile, fp32 MFMA) dense path: dense_mfma.hip -----------
 struct DenseMfmaPlan {
   int q_tiles, grid_x, grid_y, slabs, cap, waves;
-  bool transposed;  // chunk tiles held in LDS, queries streamed (short corpus, long batch)
   long rows_per_block, rows_per_slab, ld;  // ld = leading dimension of S (n rounded up to 32 floats)
   size_t lds_scores, s_bytes, part_bytes;
 };

@@ -678,8 +678,8 @@ int amdr_dense_plan_info(const amdr_dense_t* h, int32_t nq, int32_t k, char* buf
       snprintf(buf, buf_len, "dense_panel_scores_kernel nb=%d parts=%d blocks=%d queries_per_launch=%d + %s", pp.nb,
                pp.parts, pp.m_tiles * pp.parts, m, tail);
     } else {
-      snprintf(buf, buf_len, "dense_mfma_scores_kernel %s grid=%dx%d queries_per_launch=%d + %s",
-               p.transposed ? "chunk-tiles-in-LDS" : "query-tiles-in-LDS", p.grid_x, p.grid_y, m, tail);
+      snprintf(buf, buf_len, "dense_mfma_scores_kernel query-tiles-in-LDS grid=%dx%d queries_per_launch=%d + %s",
+               p.grid_x, p.grid_y, m, tail);
     }
     return AMDR_OK;
   }

@@ -1,4 +1,6 @@
-// Dense channel, batched form: 32 queries share one pass over the chunk matrix.
+// Dense channel, batched form: 32 queries share one pass over the chunk matrix (5-95 queries per
+// call, and the 32-queries-per-pass scan of a large matrix; batches of >= 96 queries take
+// dense_panel.hip).
 //
 // Same contract as dense.hip (exact inner-product top-k behind faiss
 // `index.search`, legalrag/retrieval/dense_retriever.py:42) for query batches.
@@ -100,15 +102,9 @@ __device__ __forceinline__ int stage_off(int row, int slot) { return row * 128 +
 
 // grid: (x = row slabs, y = 32-query tiles).
 // LDS: Q tile row-major [32][d/4] float4, slots XOR-swizzled per row (d*128 B) + per wave one private 4-KiB chunk stage.
-//
-// TR = true swaps the roles (the MFMA is symmetric in its two operands): the caller passes
-// the QUERY matrix as the streamed operand X and the CHUNK matrix as the tiled operand Q, so
-// a block keeps 32 chunk rows in LDS and its waves stream query tiles past them.  That is the
-// better decomposition for a short corpus under a long query batch (UCC-en: 19 row tiles x
-// 292 query tiles — 19 does not split evenly over 8 waves, 292 does).  The accumulator then
-// holds C[chunk row][query]; it is transposed through the wave's own stage so that S keeps
-// its [query][chunk row] layout and 128-byte stores.
-template <int D8, int WAVES, bool TR>  // D8 = d / 8; WAVES = 8 when the Q tile leaves room for 8 stages (d <= 768)
+// (Round 1 also ran this kernel with the roles swapped — chunk tiles in LDS, queries streamed — for
+// short corpora under long batches; dense_panel.hip replaced that orientation and it was removed.)
+template <int D8, int WAVES>  // D8 = d / 8; WAVES = 8 when the Q tile leaves room for 8 stages (d <= 768)
 __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const float* __restrict__ X, long n,
                                                                  const float* __restrict__ Q, int nq,
                                                                  long rows_per_block, int gx, int gy, long ldS,
@@ -262,16 +258,10 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
         }
     wave_lds_fence();
 #pragma unroll
-    for (int p = 0; p < 16; ++p) {
-      if (!TR) {  // LDS tile = queries q0 + ti, streamed = chunk rows r0 + tj
-        const int ti = 2 * p + h, tj = i;
-        const float v = tf[ti * 32 + (tj ^ ti)];
-        if (q0 + ti < nq && r0 + tj < row_hi) S[(size_t)(q0 + ti) * ldS + r0 + tj] = v;
-      } else {  // LDS tile = chunk rows q0 + ti, streamed = queries r0 + tj
-        const int tj = 2 * p + h, ti = i;
-        const float v = tf[ti * 32 + (tj ^ ti)];
-        if (r0 + tj < row_hi && q0 + ti < nq) S[(size_t)(r0 + tj) * ldS + q0 + ti] = v;
-      }
+    for (int p = 0; p < 16; ++p) {  // LDS tile = queries q0 + ti, streamed = chunk rows r0 + tj
+      const int ti = 2 * p + h, tj = i;
+      const float v = tf[ti * 32 + (tj ^ ti)];
+      if (q0 + ti < nq && r0 + tj < row_hi) S[(size_t)(q0 + ti) * ldS + r0 + tj] = v;
     }
     wave_lds_fence();  // the next tile's first chunk is staged over T
   }
@@ -444,12 +434,11 @@ static constexpr int scores_waves(int d) {
   return w > 8 ? 8 : w;  // two waves per SIMD wherever the LDS tile leaves room (every d <= 1024 with one stage)
 }
 
-// One orientation of the tile product: `tiles` 32-row tiles of the streamed operand are cut
-// into gx slabs per tile of the operand held in LDS (`fixed_tiles` of them).  One block per CU
-// is resident (the LDS tile fills most of the LDS), a block costs (tiles per wave) tile-times
-// plus ~1/4 tile-time to stage its LDS tile, and blocks run in rounds of 256.  Returns the
-// slab count with the smallest estimate.
-static long plan_orientation(long tiles, long fixed_tiles, int waves, double* est_out) {
+// `tiles` 32-row tiles of the chunk matrix are cut into gx slabs per query tile held in LDS
+// (`q_tiles` of them).  One block per CU is resident (the LDS tile fills most of the LDS), a block
+// costs (tiles per wave) tile-times plus ~1/4 tile-time to stage its LDS tile, and blocks run in
+// rounds of 256.  Returns the slab count with the smallest estimate.
+static long plan_slabs(long tiles, long q_tiles, int waves) {
   long gx_max = (tiles + waves - 1) / waves;  // at least one tile per wave
   if (gx_max < 1) gx_max = 1;
   long gx = 1;
@@ -457,47 +446,26 @@ static long plan_orientation(long tiles, long fixed_tiles, int waves, double* es
   for (long g = 1; g <= gx_max && g <= 4096; ++g) {
     long tpb = (tiles + g - 1) / g;
     long per_wave = (tpb + waves - 1) / waves;
-    long rounds = (fixed_tiles * g + 255) / 256;
+    long rounds = (q_tiles * g + 255) / 256;
     double est = (double)rounds * ((double)per_wave + 0.25);
     if (est < best - 1e-9) {
       best = est;
       gx = g;
     }
   }
-  *est_out = best;
   return gx;
 }
 
 void dense_mfma_plan(long n, int d, int nq, int k, DenseMfmaPlan* p) {
   const int kBW = scores_waves(d);
   p->q_tiles = ceil_div(nq, 32);
-  long tiles = (n + 31) / 32;
-  double est_n, est_t;
-  long gx = plan_orientation(tiles, p->q_tiles, kBW, &est_n);
-  // Roles swapped (chunk tiles in LDS, queries streamed): taken when it balances clearly better,
-  // which is the short-corpus / long-batch case; never for a corpus of more than 64 Ki rows.
-  // AMDR_DENSE_ORIENT=n|t pins the choice (tests drive both orientations over the same shapes).
-  p->transposed = false;
-  const char* pin = getenv("AMDR_DENSE_ORIENT");
-  const bool pin_t = pin && pin[0] == 't', pin_n = pin && pin[0] == 'n';
-  if (tiles <= 2048 && !pin_n && (pin_t || p->q_tiles >= kBW)) {
-    long gxt = plan_orientation(p->q_tiles, tiles, kBW, &est_t);
-    if (pin_t || est_t < 0.9 * est_n) {
-      p->transposed = true;
-      long tpb = (p->q_tiles + gxt - 1) / gxt;
-      tpb = ((tpb + kBW - 1) / kBW) * kBW;
-      p->rows_per_block = tpb * 32;
-      p->grid_x = (int)(((long)nq + p->rows_per_block - 1) / p->rows_per_block);
-      p->grid_y = (int)tiles;
-    }
-  }
-  if (!p->transposed) {
-    long tiles_per_block = (tiles + gx - 1) / gx;
-    tiles_per_block = ((tiles_per_block + kBW - 1) / kBW) * kBW;
-    p->rows_per_block = tiles_per_block * 32;
-    p->grid_x = (int)((n + p->rows_per_block - 1) / p->rows_per_block);
-    p->grid_y = p->q_tiles;
-  }
+  const long tiles = (n + 31) / 32;
+  const long gx = plan_slabs(tiles, p->q_tiles, kBW);
+  long tiles_per_block = (tiles + gx - 1) / gx;
+  tiles_per_block = ((tiles_per_block + kBW - 1) / kBW) * kBW;
+  p->rows_per_block = tiles_per_block * 32;
+  p->grid_x = (int)((n + p->rows_per_block - 1) / p->rows_per_block);
+  p->grid_y = p->q_tiles;
   if (p->grid_x < 1) p->grid_x = 1;
   p->lds_scores = (size_t)d * 32 * sizeof(float) + (size_t)kBW * kStageBufs * kStageBytes;
   p->waves = kBW;
@@ -511,28 +479,22 @@ void dense_mfma_plan(long n, int d, int nq, int k, DenseMfmaPlan* p) {
   if (p->slabs < 1) p->slabs = 1;
   p->cap = topk_cap(k);
   // rows of S start on 128-byte lines: the 32-column store segments are then whole lines
-  // (unaligned, the transposed launch wrote 1.58x its bytes as partial lines — PMC WRITE_SIZE)
   p->ld = (n + 31) / 32 * 32;
   p->s_bytes = (size_t)nq * (size_t)p->ld * sizeof(float);
   p->part_bytes = (size_t)p->slabs * nq * k * sizeof(C32);
 }
 
-template <int D8, int WAVES, bool TR>
+template <int D8, int WAVES>
 static int launch_scores(const DenseMfmaPlan& p, const float* X, long n, const float* Q, int nq, float* S,
                          hipStream_t st) {
   // 128-160 KiB of dynamic LDS needs the opt-in.  The attribute belongs to the (function, device)
   // pair, the C ABI takes a device ordinal, and setting it is cheap: set on every launch for the
   // current device rather than remembering "done" per process.
-  AMDR_HIP(hipFuncSetAttribute((const void*)dense_mfma_scores_kernel<D8, WAVES, TR>,
+  AMDR_HIP(hipFuncSetAttribute((const void*)dense_mfma_scores_kernel<D8, WAVES>,
                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                D8 * 8 * 32 * (int)sizeof(float) + WAVES * kStageBufs * kStageBytes));
-  // TR: the query matrix is the streamed operand, the chunk matrix the tiled one
-  if (TR)
-    hipLaunchKernelGGL((dense_mfma_scores_kernel<D8, WAVES, true>), dim3(p.grid_x * p.grid_y), dim3(WAVES * 64),
-                       p.lds_scores, st, Q, (long)nq, X, (int)n, p.rows_per_block, p.grid_x, p.grid_y, p.ld, S);
-  else
-    hipLaunchKernelGGL((dense_mfma_scores_kernel<D8, WAVES, false>), dim3(p.grid_x * p.grid_y), dim3(WAVES * 64),
-                       p.lds_scores, st, X, n, Q, nq, p.rows_per_block, p.grid_x, p.grid_y, p.ld, S);
+  hipLaunchKernelGGL((dense_mfma_scores_kernel<D8, WAVES>), dim3(p.grid_x * p.grid_y), dim3(WAVES * 64),
+                     p.lds_scores, st, X, n, Q, nq, p.rows_per_block, p.grid_x, p.grid_y, p.ld, S);
   return AMDR_OK;
 }
 
@@ -540,10 +502,9 @@ int dense_mfma_launch_scores(const DenseMfmaPlan& p, const float* X, long n, int
                              hipStream_t st) {
   int rc = AMDR_OK;
   switch (d) {
-#define AMDR_CASE(D)                                                               \
-  case D:                                                                          \
-    rc = p.transposed ? launch_scores<D / 8, scores_waves(D), true>(p, X, n, Q, nq, S, st)   \
-                      : launch_scores<D / 8, scores_waves(D), false>(p, X, n, Q, nq, S, st); \
+#define AMDR_CASE(D)                                                          \
+  case D:                                                                     \
+    rc = launch_scores<D / 8, scores_waves(D)>(p, X, n, Q, nq, S, st);        \
     break;
     AMDR_CASE(64) AMDR_CASE(128) AMDR_CASE(192) AMDR_CASE(256) AMDR_CASE(320) AMDR_CASE(384)
     AMDR_CASE(448) AMDR_CASE(512) AMDR_CASE(576) AMDR_CASE(640) AMDR_CASE(704) AMDR_CASE(768)

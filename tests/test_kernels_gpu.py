@@ -99,29 +99,14 @@ def test_dense_fuzz_shapes(nat):
         check_dense(nat, X, Q, k)
 
 
-@pytest.mark.parametrize("orient", ["t", "n"])
-def test_dense_batched_both_orientations(nat, orient, monkeypatch):
-    """The batched form has two decompositions (chunk tiles or query tiles held in LDS; the
-    planner picks by balance).  Pin each in turn over shapes with partial tiles on both sides."""
-    monkeypatch.setenv("AMDR_DENSE_ORIENT", orient)
+def test_dense_tile_kernel_long_batches(nat, monkeypatch):
+    """The 32-query-tile kernel (dense_mfma.hip) serves 5-95 queries by default; AMDR_DENSE_PANEL=0
+    pins it for long batches too (partial tiles on both sides, several row slabs)."""
+    monkeypatch.setenv("AMDR_DENSE_PANEL", "0")
     rng = np.random.default_rng(77)
     for n, d, nq, k in [(591, 768, 2500, 10), (100, 64, 700, 5), (1999, 384, 1030, 20), (33, 1024, 300, 50),
                         (40, 832, 333, 7), (1, 128, 40, 3), (65, 192, 5, 80), (4097, 256, 95, 10)]:
         check_dense(nat, unit_rows(rng, n, d), unit_rows(rng, nq, d), k)
-
-
-def test_dense_orientations_agree_bitwise(nat, monkeypatch):
-    """Both decompositions run the same k-ordered fp32 MFMA chain per (query, row): identical bits."""
-    rng = np.random.default_rng(78)
-    X, Q = unit_rows(rng, 591, 768), unit_rows(rng, 1500, 768)
-    out = {}
-    for orient in ("n", "t"):
-        monkeypatch.setenv("AMDR_DENSE_ORIENT", orient)
-        idx = nat.DenseIndex(X)
-        out[orient] = idx.search(Q, 10)
-        idx.close()
-    assert np.array_equal(out["n"][1], out["t"][1])
-    assert np.array_equal(out["n"][0], out["t"][0])
 
 
 @pytest.mark.parametrize("parts", [None, "lo", "hi"])
