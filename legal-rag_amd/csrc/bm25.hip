@@ -297,6 +297,13 @@ __global__ __launch_bounds__(WAVES * 64) void bm25_score_topk_kernel(
     for (int i = tid; i < m; i += NT) scores_out[(size_t)qi * n_docs + lo + i] = sc[i];
   }
   if (!part && !fin_ids) return;
+#if defined(AMDR_BM_ABL) && AMDR_BM_ABL == 3  // timing-only build: no ranking
+  if (fin_ids && tid < k) {
+    fin_ids[(size_t)qi * k + tid] = tid;
+    fin_scores[(size_t)qi * k + tid] = sc[tid];
+  }
+  return;
+#endif
 
   WaveTopK<C64> tk;
   tk.init(lists + (size_t)wave * cap, cap, k);
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(WAVES * 64) void bm25_score_topk_kernel(
     const int nv = (m + 63) >> 6;
     int got = -1;
     if (k <= 64 && use_select) {  // fp32-image candidates + exact check; -1 = undecided, fall through to the exact rounds
-      C32* scratch = reinterpret_cast<C32*>(tk.buf + k);
+      C32* scratch = reinterpret_cast<C32*>(tk_ps);  // 64 x 8 B: the token table is dead once the slab is scored
       if (nv <= 4)
         got = bm25_select_f32<4>(sc, m, k, lo, lane, scratch, tk.buf);
       else if (nv <= 8)
@@ -437,7 +444,7 @@ void bm_plan(int64_t n_docs, int nq, int k, BmPlan* p) {
   const int64_t n = n_docs > 0 ? n_docs : 1;
   auto balanced = [&](int slab_max) {
     p->nslabs = (int)((n + slab_max - 1) / slab_max);
-    p->slab = (int)(((n + p->nslabs - 1) / p->nslabs + 63) / 64 * 64);
+    p->slab = (int)(((n + p->nslabs - 1) / p->nslabs + 15) / 16 * 16);
     if (p->slab > slab_max) p->slab = slab_max;
     p->nslabs = (int)((n + p->slab - 1) / p->slab);
   };
@@ -446,8 +453,7 @@ void bm_plan(int64_t n_docs, int nq, int k, BmPlan* p) {
   if (!argmax) balanced(kSlabMax);
   p->waves = 1;
   p->cap_merge = topk_cap(k);
-  // arg-max path: k result slots + 32 slots (= 64 C32 entries) of scratch for bm25_select_f32
-  p->cap = argmax ? ((k <= 16 ? 16 : kBmArgmaxK) + 32) : p->cap_merge;
+  p->cap = argmax ? (k <= 16 ? 16 : kBmArgmaxK) : p->cap_merge;
   p->lds = (size_t)p->slab * sizeof(double) + (size_t)p->waves * p->cap * sizeof(C64) + 4 * sizeof(int) +
            64 * (2 * sizeof(long) + sizeof(double)) + 8;
   p->part_bytes = (size_t)p->nslabs * nq * k * sizeof(C64);
