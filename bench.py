@@ -445,6 +445,15 @@ def run_api(torch, local):
                 dt = time.perf_counter() - t
                 out["search_batch_dense_bm25"] = {"queries": len(qs), "seconds": dt, "queries_per_s": len(qs) / dt,
                                                   "hits_returned": sum(len(h) for h in hits)}
+                big = qs * 8
+                r.search_batch_arrays(big[:256], top_k=10)
+                t = time.perf_counter()
+                col = r.search_batch_arrays(big, top_k=10)
+                dt = time.perf_counter() - t
+                out["search_batch_arrays_dense_bm25"] = {
+                    "queries": len(big), "seconds": dt, "queries_per_s": len(big) / dt,
+                    "hits_returned": int(col["count"].sum()),
+                    "note": "columnar results (no RetrievalHit objects); tokenisation and the stand-in encoder included"}
     return out
 
 

@@ -435,7 +435,7 @@ class HybridRetriever:
             return None
         return store, self.bm25, col
 
-    def _batch_native(self, questions: Sequence[str], eff: int, native, min_final: float):
+    def _batch_native(self, questions: Sequence[str], eff: int, native, min_final: float, arrays: bool = False):
         """Embed / tokenise on the host, then dense + BM25 (+ MaxSim) top-k -> fuse -> min_final
         count for the whole batch on torch's current stream, one synchronise, results built once.
         Returns ([fused hits with score >= min_final per question], (t_after_dense_prep, t_after_bm25_prep,
@@ -450,6 +450,8 @@ class HybridRetriever:
             rest = [i for i in range(len(questions)) if i not in set(blank)]
             out = [None] * len(questions)
             stamps = (time.time(),) * 3
+            if arrays:
+                raise ValueError("search_batch_arrays: empty questions are not supported in the columnar form")
             for idxs, nat in ((blank, (store, bm, None)), (rest, native)):
                 if idxs:
                     part, stamps = self._batch_native([questions[i] for i in idxs], eff, nat, min_final)
@@ -492,6 +494,8 @@ class HybridRetriever:
             # ONE synchronise: the D2H copies below run on the same stream and block until the data is there
             ids, vals, mask, cnt = (res.ids.cpu().numpy(), res.vals.cpu().numpy(), res.mask.cpu().numpy(),
                                     res.count.cpu().numpy())
+        if arrays:
+            return (ids, vals, mask, cnt, np.asarray(exact, dtype=bool)), (t1, t2, t3)
         chunks = store.chunks
         out = []
         for qi in range(len(questions)):
@@ -517,3 +521,24 @@ class HybridRetriever:
                                "over the same chunk list")
         outs, _ = self._batch_native(list(questions), eff, native, float(getattr(rcfg, "min_final_score", 0.0)))
         return [_dedup_keep_best(hits)[:top_k] for hits in outs]
+
+    def search_batch_arrays(self, questions: Sequence[str], top_k: int = 10) -> Dict[str, Any]:
+        """`search_batch` without building RetrievalHit objects (pydantic construction, not the GPU, bounds
+        `search_batch` at a few thousand queries/s): columnar results for bulk callers (evaluation sweeps,
+        offline scoring).  rows[q, j] indexes `self.dense.store.chunks`; entries j >= count[q] are -1 / 0.
+        The rows of one index are distinct chunks, so the dedup step of search() has nothing to merge."""
+        rcfg = self.cfg.retrieval
+        top_k = max(1, int(top_k))
+        eff = int(getattr(rcfg, "top_k", top_k * 8) or (top_k * 8))
+        eff = min(max(eff, top_k), _native.MAX_K)
+        native = self._native_channels(eff)
+        if native is None:
+            raise RuntimeError("search_batch_arrays requires this package's own retrievers built over the same chunk list")
+        (ids, vals, mask, cnt, exact), _ = self._batch_native(list(questions), eff, native,
+                                                                float(getattr(rcfg, "min_final_score", 0.0)), arrays=True)
+        w = min(top_k, ids.shape[1])
+        keep = np.arange(w)[None, :] < np.minimum(cnt, w)[:, None]
+        return {"rows": np.where(keep, ids[:, :w], -1), "scores": np.where(keep, vals[:, :w, _native.FV["score"]], 0.0),
+                "count": np.minimum(cnt, w).astype(np.int32), "channel_mask": np.where(keep, mask[:, :w], 0),
+                "values": vals[:, :w], "value_names": dict(_native.FV), "zh_exact": exact,
+                "chunks": native[0].chunks}

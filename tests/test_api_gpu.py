@@ -303,6 +303,28 @@ def test_search_and_search_batch_from_two_threads(ucc_index):
     assert not errors, errors[:5]
 
 
+def test_search_batch_arrays_equals_search_batch(ucc_index):
+    from legal_rag_amd.retrieval.hybrid_retriever import HybridRetriever
+    cfg, _ = ucc_index
+    cfg2 = copy.deepcopy(cfg)
+    cfg2.retrieval.enable_rerank = False
+    r = HybridRetriever(cfg2)
+    qs = QUESTIONS * 3
+    hits = r.search_batch(qs, top_k=10)
+    col = r.search_batch_arrays(qs, top_k=10)
+    assert col["rows"].shape == (len(qs), 10) and col["zh_exact"].all()
+    for q, hs in enumerate(hits):
+        n = int(col["count"][q])
+        assert n == len(hs)
+        assert [col["chunks"][int(i)].id for i in col["rows"][q, :n]] == [h.chunk.id for h in hs]
+        assert col["scores"][q, :n].tolist() == [h.score for h in hs]
+        assert (col["rows"][q, n:] == -1).all()
+        for j, h in enumerate(hs):
+            assert col["values"][q, j, col["value_names"]["rrf_norm"]] == h.score_breakdown["rrf_norm"]
+    with pytest.raises(ValueError):
+        r.search_batch_arrays(["ok", "  "], top_k=5)
+
+
 def test_error_conventions(tmp_path):
     """Missing dense files -> FileNotFoundError; missing bm25 -> RuntimeError;
     missing colbert meta is swallowed at construction."""
