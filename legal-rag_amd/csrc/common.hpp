@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 
@@ -64,6 +65,14 @@ inline int next_pow2(int v) {
 inline int topk_cap(int k) { return next_pow2(k + 64) < 128 ? 128 : next_pow2(k + 64); }
 
 int check_device(int device);
+
+// A chunk matrix larger than the 256 MiB Infinity Cache is streamed with the non-temporal policy
+// (read once per scan; nothing to keep on-die).  AMDR_DENSE_NT=0|1 pins the choice.
+inline bool dense_stream_nontemporal(long n, int d) {
+  const char* e = getenv("AMDR_DENSE_NT");
+  if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+  return (size_t)n * (size_t)d * sizeof(float) > ((size_t)256 << 20);
+}
 
 // ---- batched (32-query tile, fp32 MFMA) dense path: dense_mfma.hip -----------
 struct DenseMfmaPlan {

@@ -97,14 +97,15 @@ __device__ __forceinline__ int stage_off(int row, int slot) { return row * 128 +
 #if defined(AMDR_ABLATE) && AMDR_ABLATE == 2  // timing-only build: no X traffic (registers filled from an address hash)
 #define AMDR_LDX(PTR) ([&] { v4f z_; z_.x = z_.y = z_.z = z_.w = (float)(((size_t)(PTR)) & 1023) * 1e-3f; return z_; }())
 #else
-#define AMDR_LDX(PTR) (*reinterpret_cast<const v4f*>(PTR))
+// NTL (template constant): non-temporal policy for a matrix beyond the Infinity Cache (common.hpp)
+#define AMDR_LDX(PTR) (NTL ? __builtin_nontemporal_load(reinterpret_cast<const v4f*>(PTR)) : *reinterpret_cast<const v4f*>(PTR))
 #endif
 
 // grid: (x = row slabs, y = 32-query tiles).
 // LDS: Q tile row-major [32][d/4] float4, slots XOR-swizzled per row (d*128 B) + per wave one private 4-KiB chunk stage.
 // (Round 1 also ran this kernel with the roles swapped — chunk tiles in LDS, queries streamed — for
 // short corpora under long batches; dense_panel.hip replaced that orientation and it was removed.)
-template <int D8, int WAVES>  // D8 = d / 8; WAVES = 8 when the Q tile leaves room for 8 stages (d <= 768)
+template <int D8, int WAVES, bool NTL>  // NTL: non-temporal loads of the streamed operand; D8 = d / 8; WAVES = 8 when the Q tile leaves room for 8 stages (d <= 768)
 __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const float* __restrict__ X, long n,
                                                                  const float* __restrict__ Q, int nq,
                                                                  long rows_per_block, int gx, int gy, long ldS,
@@ -484,16 +485,16 @@ void dense_mfma_plan(long n, int d, int nq, int k, DenseMfmaPlan* p) {
   p->part_bytes = (size_t)p->slabs * nq * k * sizeof(C32);
 }
 
-template <int D8, int WAVES>
+template <int D8, int WAVES, bool NTL>
 static int launch_scores(const DenseMfmaPlan& p, const float* X, long n, const float* Q, int nq, float* S,
                          hipStream_t st) {
   // 128-160 KiB of dynamic LDS needs the opt-in.  The attribute belongs to the (function, device)
   // pair, the C ABI takes a device ordinal, and setting it is cheap: set on every launch for the
   // current device rather than remembering "done" per process.
-  AMDR_HIP(hipFuncSetAttribute((const void*)dense_mfma_scores_kernel<D8, WAVES>,
+  AMDR_HIP(hipFuncSetAttribute((const void*)dense_mfma_scores_kernel<D8, WAVES, NTL>,
                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                D8 * 8 * 32 * (int)sizeof(float) + WAVES * kStageBufs * kStageBytes));
-  hipLaunchKernelGGL((dense_mfma_scores_kernel<D8, WAVES>), dim3(p.grid_x * p.grid_y), dim3(WAVES * 64),
+  hipLaunchKernelGGL((dense_mfma_scores_kernel<D8, WAVES, NTL>), dim3(p.grid_x * p.grid_y), dim3(WAVES * 64),
                      p.lds_scores, st, X, n, Q, nq, p.rows_per_block, p.grid_x, p.grid_y, p.ld, S);
   return AMDR_OK;
 }
@@ -501,10 +502,12 @@ static int launch_scores(const DenseMfmaPlan& p, const float* X, long n, const f
 int dense_mfma_launch_scores(const DenseMfmaPlan& p, const float* X, long n, int d, const float* Q, int nq, float* S,
                              hipStream_t st) {
   int rc = AMDR_OK;
+  const bool nt = dense_stream_nontemporal(n, d);
   switch (d) {
 #define AMDR_CASE(D)                                                          \
   case D:                                                                     \
-    rc = launch_scores<D / 8, scores_waves(D)>(p, X, n, Q, nq, S, st);        \
+    rc = nt ? launch_scores<D / 8, scores_waves(D), true>(p, X, n, Q, nq, S, st)   \
+            : launch_scores<D / 8, scores_waves(D), false>(p, X, n, Q, nq, S, st); \
     break;
     AMDR_CASE(64) AMDR_CASE(128) AMDR_CASE(192) AMDR_CASE(256) AMDR_CASE(320) AMDR_CASE(384)
     AMDR_CASE(448) AMDR_CASE(512) AMDR_CASE(576) AMDR_CASE(640) AMDR_CASE(704) AMDR_CASE(768)
