@@ -322,11 +322,19 @@ __global__ __launch_bounds__(WAVES * 64) void scores_slab_topk_kernel(const floa
     }
   }
   if (!done) {
-    for (long base = lo + (long)wave * 64; base < hi; base += (long)WAVES * 64) {
-      const long r = base + lane;
-      const bool v = r < hi;
-      C32 c = v ? C32::make(row[r], (u32)r) : C32::pad();
-      tk.push_lanes(c, v, lane);
+    // S is read exactly once: 16-byte non-temporal loads, four consecutive rows per lane (slabs start
+    // on multiples of 64 rows and S rows on 128-byte lines, so every float4 below `hi` rounded up to 4
+    // lies inside the padded row)
+    for (long base = lo + (long)wave * 256; base < hi; base += (long)WAVES * 256) {
+      const long r0 = base + 4 * lane;
+      const v4f z = {0.f, 0.f, 0.f, 0.f};
+      const v4f x = (r0 < hi) ? __builtin_nontemporal_load(reinterpret_cast<const v4f*>(row + r0)) : z;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const long r = r0 + e;
+        const bool v = r < hi;
+        tk.push_lanes(v ? C32::make(x[e], (u32)r) : C32::pad(), v, lane);
+      }
     }
     tk.finalize(lane);
   }
@@ -364,7 +372,7 @@ __device__ __forceinline__ int select_row_pair(const float* __restrict__ S, long
   for (int u = 0; u < V / 4; ++u) {
     const long c0 = 128L * u + 4 * j;
     const v4f z = {0.f, 0.f, 0.f, 0.f};
-    blk[u] = (has_q && c0 < ldS) ? *reinterpret_cast<const v4f*>(row + c0) : z;
+    blk[u] = (has_q && c0 < ldS) ? __builtin_nontemporal_load(reinterpret_cast<const v4f*>(row + c0)) : z;  // read once
   }
 #pragma unroll
   for (int u = 0; u < V / 4; ++u)
