@@ -223,6 +223,21 @@ def test_dense_add_and_read_rows(nat):
     assert np.array_equal(i, ei)
 
 
+def test_dense_nontemporal_policy_changes_nothing_but_speed(nat, monkeypatch):
+    """Matrices beyond the Infinity Cache are streamed with non-temporal loads (AMDR_DENSE_NT pins the
+    choice): a cache policy, not arithmetic — GEMV scan, tile kernel and top-k passes give identical bits."""
+    rng = np.random.default_rng(21)
+    X = unit_rows(rng, 20000, 768)
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("AMDR_DENSE_NT", flag)
+        idx = nat.DenseIndex(X)
+        out[flag] = [idx.search(unit_rows(np.random.default_rng(5), nq, 768), k) for nq, k in ((1, 10), (4, 80), (33, 10))]
+        idx.close()
+    for a, b in zip(out["0"], out["1"]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
 def test_handles_on_a_non_default_device(nat):
     """The C ABI takes a device ordinal; kernels that need the > 64 KiB dynamic-LDS opt-in set the
     attribute for the CURRENT device on every launch (a per-process "done" flag made a second device
