@@ -49,25 +49,29 @@ typedef float ms4f __attribute__((ext_vector_type(4)));
 // a[bi][t] / q[bj][t]: the lane's 16-B slot 4t + kq of document-token row 16 bi + i16 / query-token
 // row 16 bj + i16.  Returns, per query-token block bj, the maximum over this lane's 8 document
 // tokens (rows 16 bi + 4 kq + r), rows >= remain masked out.
+// NBI = 1: the tile holds at most 16 document tokens (the tail of a document): the second row block
+// would be masked out entirely, so its 64 MFMAs (and the caller's 8 fragment reads) are skipped —
+// same results, and documents are short (Civil-Code articles: 77 tokens on average, 17 % of the
+// 32-token tile slots were padding).
+template <int NBI>
 __device__ __forceinline__ void ms_tile(const ms4f (&a)[2][8], const ms4f (&q)[2][8], int kq, int remain,
                                         float (&best)[2]) {
-  f32x4 acc[2][2];
+  f32x4 acc[NBI][2];
 #pragma unroll
-  for (int bi = 0; bi < 2; ++bi)
+  for (int bi = 0; bi < NBI; ++bi)
 #pragma unroll
     for (int bj = 0; bj < 2; ++bj) acc[bi][bj] = f32x4{0.f, 0.f, 0.f, 0.f};
-#define AMDR_MS_K(T, COMP)                                                                                  \
-  acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][T].COMP, q[0][T].COMP, acc[0][0], 0, 0, 0);         \
-  acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][T].COMP, q[1][T].COMP, acc[0][1], 0, 0, 0);         \
-  acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][T].COMP, q[0][T].COMP, acc[1][0], 0, 0, 0);         \
-  acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][T].COMP, q[1][T].COMP, acc[1][1], 0, 0, 0);
 #pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    AMDR_MS_K(t, x) AMDR_MS_K(t, y) AMDR_MS_K(t, z) AMDR_MS_K(t, w)
-  }
-#undef AMDR_MS_K
+  for (int t = 0; t < 8; ++t)
 #pragma unroll
-  for (int bi = 0; bi < 2; ++bi)
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int bi = 0; bi < NBI; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj)
+          acc[bi][bj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[bi][t][e], q[bj][t][e], acc[bi][bj], 0, 0, 0);
+#pragma unroll
+  for (int bi = 0; bi < NBI; ++bi)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool off = remain < 32 && (16 * bi + 4 * kq + r) >= remain;
@@ -128,7 +132,10 @@ __global__ __launch_bounds__(256) void maxsim_scores_kernel(const float* __restr
   for (int tok0 = 0; tok0 < len; tok0 += 32) {
     ms4f af[2][8];  // rows past the document end are clamped here and masked in ms_tile
     ms_load_frag(D, t_lo + tok0, t_hi - 1, i16, kq, false, af);
-    ms_tile(af, qf, kq, len - tok0, best);
+    if (len - tok0 <= 16)
+      ms_tile<1>(af, qf, kq, len - tok0, best);
+    else
+      ms_tile<2>(af, qf, kq, len - tok0, best);
   }
   const float total = ms_finish(best, i16, kq, q_len);
   if (lane == 0) scores[(size_t)qi * n_docs + doc] = total;
@@ -219,12 +226,19 @@ __global__ __launch_bounds__(kMsQ * 64) void maxsim_scores_blocked_kernel(const 
     if (has_next) { AMDR_MS_LOAD(nt_lo, nlen, ntok) }
 
     ms4f af[2][8];
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
+    if (len - tok0 <= 16) {  // wave-uniform: the tail of a document fits one 16-token row block
 #pragma unroll
       for (int t = 0; t < 8; ++t)
-        af[b][t] = *reinterpret_cast<const ms4f*>(tile[buf] + ms_tile_off(16 * b + i16, 4 * t + kq));
-    ms_tile(af, qf, kq, len - tok0, best);
+        af[0][t] = *reinterpret_cast<const ms4f*>(tile[buf] + ms_tile_off(i16, 4 * t + kq));
+      ms_tile<1>(af, qf, kq, len - tok0, best);
+    } else {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          af[b][t] = *reinterpret_cast<const ms4f*>(tile[buf] + ms_tile_off(16 * b + i16, 4 * t + kq));
+      ms_tile<2>(af, qf, kq, len - tok0, best);
+    }
     if (ntok == 0) {  // last tile of this document
       const float total = ms_finish(best, i16, kq, q_len);
       if (live && lane == 0) scores[(size_t)qi * n_docs + doc] = total;
