@@ -60,16 +60,18 @@ __device__ __forceinline__ long lower_bound_i32(const int* __restrict__ a, long 
 // ~6 NV + 25 vector instructions per round; the staged selector of topk.hpp sorts 128-bit
 // candidates through LDS twice (measured 65 of the kernel's 98 us per 9 344 queries).
 // -0.0 is folded to +0.0 and NaN ranks below every real score, as C64::make orders them.
+// score as it is ranked: -0.0 -> +0.0, NaN below every real score
+__device__ __forceinline__ double bm25_ranked(double raw) {
+  const double x = raw + 0.0;
+  return (x != x) ? -DBL_MAX : x;
+}
+
 template <int NV>
 __device__ __forceinline__ int bm25_argmax_rounds(const double* sc, int m, int k, long lo, int lane, C64* out) {
   const double ninf = -INFINITY;
   double sv[NV];
 #pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    const int i = lane + 64 * v;
-    const double x = (i < m) ? sc[i] + 0.0 : ninf;
-    sv[v] = (x != x) ? -DBL_MAX : x;
-  }
+  for (int v = 0; v < NV; ++v) sv[v] = (lane + 64 * v < m) ? bm25_ranked(sc[lane + 64 * v]) : ninf;
   int got = 0;
 #if defined(AMDR_BM_ABL) && AMDR_BM_ABL == 1
   for (int it = 0; it < 1; ++it) {
@@ -111,14 +113,14 @@ __device__ __forceinline__ int bm25_argmax_rounds(const double* sc, int m, int k
 // (mass ties at the cut: e.g. every document at score 0) -> -1 as well.
 template <int NV>
 __device__ __forceinline__ int bm25_select_f32(const double* sc, int m, int k, long lo, int lane, C32* scratch,
-                                               C64* out) {
+                                               double* xs /* [64] exact scores of the survivors */, C64* out) {
   // fp32 images as order-preserving 32-bit keys (ord32: -0.0 -> +0.0, NaN lowest; 0 = no document)
   u32 img[NV];
   u32 lb = 0u;
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     const int i = lane + 64 * v;
-    img[v] = (i < m) ? ord32((float)sc[i]) : 0u;
+    img[v] = (i < m) ? ord32((float)sc[lane + 64 * v]) : 0u;
     lb = img[v] > lb ? img[v] : lb;
   }
   // The cut: the k-th largest of the 64 lane bests bounds the k-th best image from below.  It is
@@ -131,19 +133,76 @@ __device__ __forceinline__ int bm25_select_f32(const double* sc, int m, int k, l
     const u32 cand = T | (1u << bit);
     T = (__popcll(__ballot(lb >= cand)) >= k) ? cand : T;
   }
+  // Survivors: key = image | ~document (16 bits: a slab has <= 2 048) | slot; the slot finds the
+  // survivor's exact fp64 score (parked beside the key) again after the sort.
   int cnt = 0;
+  bool overflow = false;
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     const bool pass = img[v] != 0u && img[v] >= T;
     const u64 mk = __ballot(pass);
     const int tot = __popcll(mk);
-    if (cnt + tot > 64) return -1;
-    if (pass) {
-      C32 c;
-      c.c = ((u64)img[v] << 32) | (u64)(0xffffffffu - (u32)(lane + 64 * v));
-      scratch[cnt + (int)__builtin_amdgcn_mbcnt_hi((u32)(mk >> 32), __builtin_amdgcn_mbcnt_lo((u32)mk, 0u))] = c;
+    overflow = overflow || cnt + tot > 64;
+    if (!overflow) {
+      if (pass) {
+        const int at = cnt + (int)__builtin_amdgcn_mbcnt_hi((u32)(mk >> 32), __builtin_amdgcn_mbcnt_lo((u32)mk, 0u));
+        C32 c;
+        c.c = ((u64)img[v] << 32) | (u64)(((0xffffu - (u32)(lane + 64 * v)) << 8) | (u32)at);
+        scratch[at] = c;
+        xs[at] = bm25_ranked(sc[lane + 64 * v]);
+      }
+      cnt += tot;
     }
-    cnt += tot;
+  }
+  if (overflow) {
+    // More than 64 documents reach the cut: a mass tie AT the cut (the common case: every document the
+    // query's tokens do not touch sits at score 0 — a third of the UCC-en evaluation queries have no token
+    // the index knows).  Documents above the cut all rank first; if the documents AT the cut share one exact
+    // fp64 score, the rest of the top k are simply the lowest ids among them.  Anything else -> undecided.
+    int above = 0;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) above += __popcll(__ballot(img[v] > T));
+    if (T == 0u || above > 64) return -1;
+    int need = k - above;  // documents still to take from the tie, lowest ids first (v-major = id order)
+    need = need < 0 ? 0 : need;
+    if (need > 0) {
+      double x0 = 0.0;
+      bool have = false;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const u64 mk = __ballot(img[v] == T);
+        if (!have && mk) {
+          x0 = __shfl(bm25_ranked(sc[lane + 64 * v]), (int)__builtin_ctzll(mk));
+          have = true;
+        }
+      }
+      u64 differ = 0ull;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) differ |= __ballot(img[v] == T && bm25_ranked(sc[lane + 64 * v]) != x0);
+      if (differ) return -1;
+    }
+    cnt = 0;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const bool hi = img[v] > T;
+      const bool eq = img[v] == T;
+      const u64 mh = __ballot(hi), me = __ballot(eq);
+      const int before_h = (int)__builtin_amdgcn_mbcnt_hi((u32)(mh >> 32), __builtin_amdgcn_mbcnt_lo((u32)mh, 0u));
+      const int before_e = (int)__builtin_amdgcn_mbcnt_hi((u32)(me >> 32), __builtin_amdgcn_mbcnt_lo((u32)me, 0u));
+      const int nh = __popcll(mh);
+      int ne = __popcll(me);
+      ne = ne < need ? ne : need;
+      const bool take = hi || (eq && before_e < ne);
+      if (take) {
+        const int at = cnt + (hi ? before_h : nh + before_e);
+        C32 c;
+        c.c = ((u64)img[v] << 32) | (u64)(((0xffffu - (u32)(lane + 64 * v)) << 8) | (u32)at);
+        scratch[at] = c;
+        xs[at] = bm25_ranked(sc[lane + 64 * v]);
+      }
+      cnt += nh + ne;
+      need -= ne;
+    }
   }
   wave_lds_fence();
   C32 c = (lane < cnt) ? scratch[lane] : C32::pad();
@@ -154,9 +213,9 @@ __device__ __forceinline__ int bm25_select_f32(const double* sc, int m, int k, l
   else
     c = wave_sortN_desc<C32, 64>(c, lane);
   // exact scores of the survivors, and the check of every neighbouring pair up to the cut
-  const int doc = (lane < cnt) ? (int)c.id() : 0;
-  double x = sc[doc] + 0.0;
-  x = (x != x) ? -DBL_MAX : x;
+  const u32 low = (u32)c.c;
+  const int doc = (lane < cnt) ? (int)(0xffffu - (low >> 8)) : 0;
+  const double x = xs[(lane < cnt) ? (int)(low & 63u) : 0];
   const u32 im = (u32)(c.c >> 32);
   const u32 im_n = (u32)__shfl_down((int)im, 1);
   const double x_n = __shfl_down(x, 1);
@@ -167,12 +226,46 @@ __device__ __forceinline__ int bm25_select_f32(const double* sc, int m, int k, l
   return got;
 }
 
+// A query none of whose tokens has a posting in the slab leaves every score at +0.0: the ranking is the
+// slab's first k documents (ties -> lower id).  No scoring, no selection.
+__device__ __forceinline__ void bm25_all_zero_result(int m, int k, long lo, int lane, size_t row, double* fin_scores,
+                                                     long long* fin_ids, C64* part_row) {
+  for (int j = lane; j < k; j += 64) {
+    const bool v = j < m;
+    if (fin_ids) {
+      fin_scores[row * k + j] = v ? 0.0 : -DBL_MAX;
+      fin_ids[row * k + j] = v ? lo + j : -1ll;
+    } else {
+      part_row[j] = v ? C64::make(0.0, lo + j) : C64::pad();
+    }
+  }
+}
+
+// Ranking of a one-wave slab: candidates on fp32 images first
+// (k <= 64), exact arg-max rounds when that is undecided or switched off.  Returns the count.
+template <int NV>
+__device__ __forceinline__ int bm25_rank_slab(const double* sc, int m, int k, long lo, int lane, bool use_select,
+                                              C32* scratch, double* xs, C64* out) {
+  int got = -1;
+  if (k <= 64 && use_select) {
+    got = bm25_select_f32<NV>(sc, m, k, lo, lane, scratch, xs, out);
+    wave_lds_fence();
+  }
+  if (got < 0) {
+    got = bm25_argmax_rounds<NV>(sc, m, k, lo, lane, out);
+    wave_lds_fence();
+  }
+  return got;
+}
+
 // grid: (x = doc slabs, y = queries).  LDS: double sc[slab] + C64 lists[WAVES][cap] + int cnts[4] + token table [64]
 // The host launches WAVES = 1 only (one wave per (query, slab): no block barriers, no list
 // combine) — the 4-wave form the template still allows lost at every corpus size measured
 // (bm_plan).  With a single slab the final (scores, ids) are written directly and the merge
 // launch is skipped.
-template <int WAVES>
+// NVT: scores per lane the register ranking is compiled for (>= ceil(slab / 64); the host picks the bucket — one
+// kernel with every bucket inside carried the 32-register variant's VGPR count, 105, at every corpus size).
+template <int WAVES, int NVT>
 __global__ __launch_bounds__(WAVES * 64) void bm25_score_topk_kernel(
     const long long* __restrict__ term_ptr, const int* __restrict__ post_doc, const double* __restrict__ post_w,
     const double* __restrict__ idf, long n_terms, long n_docs, const int* __restrict__ q_terms,
@@ -202,6 +295,7 @@ __global__ __launch_bounds__(WAVES * 64) void bm25_score_topk_kernel(
   // Token metadata (posting range inside this slab, idf) is fetched by the lanes IN PARALLEL,
   // 64 tokens at a time, and parked in LDS: walking the tokens one by one would chain three
   // dependent global loads (term id -> term_ptr -> postings) per token, ~1.5 us each.
+  int nt_total = 0;  // block-uniform
   const long t0 = q_ptr[qi], t1 = q_ptr[qi + 1];
   for (long tb = t0; tb < t1; tb += 64) {
     const int nt_all = (int)((t1 - tb) < 64 ? (t1 - tb) : 64);
@@ -233,6 +327,7 @@ __global__ __launch_bounds__(WAVES * 64) void bm25_score_topk_kernel(
     }
     block_sync<WAVES>();
     const int nt = __builtin_amdgcn_readfirstlane(*tk_n);
+    nt_total += nt;
     if (nt == 0) {
       block_sync<WAVES>();  // the table is rewritten by the next group
       continue;
@@ -297,6 +392,12 @@ __global__ __launch_bounds__(WAVES * 64) void bm25_score_topk_kernel(
     for (int i = tid; i < m; i += NT) scores_out[(size_t)qi * n_docs + lo + i] = sc[i];
   }
   if (!part && !fin_ids) return;
+  if (nt_total == 0) {  // no token of the query has a posting here
+    if (wave == 0)
+      bm25_all_zero_result(m, k, lo, lane, (size_t)qi, fin_scores, fin_ids,
+                           part ? part + ((size_t)blockIdx.x * nq + qi) * k : nullptr);
+    return;
+  }
 #if defined(AMDR_BM_ABL) && AMDR_BM_ABL == 3  // timing-only build: no ranking
   if (fin_ids && tid < k) {
     fin_ids[(size_t)qi * k + tid] = tid;
@@ -310,42 +411,9 @@ __global__ __launch_bounds__(WAVES * 64) void bm25_score_topk_kernel(
   // Short slab and shallow k (bm_use_argmax; the serving shape is 591 docs, k = 10): bm25_argmax_rounds.
   bool done = false;
   if (WAVES == 1 && bm_use_argmax(k, slab)) {
-    const int nv = (m + 63) >> 6;
-    int got = -1;
-    if (k <= 64 && use_select) {  // fp32-image candidates + exact check; -1 = undecided, fall through to the exact rounds
-      C32* scratch = reinterpret_cast<C32*>(tk_ps);  // 64 x 8 B: the token table is dead once the slab is scored
-      if (nv <= 4)
-        got = bm25_select_f32<4>(sc, m, k, lo, lane, scratch, tk.buf);
-      else if (nv <= 8)
-        got = bm25_select_f32<8>(sc, m, k, lo, lane, scratch, tk.buf);
-      else if (nv <= 10)
-        got = bm25_select_f32<10>(sc, m, k, lo, lane, scratch, tk.buf);
-      else if (nv <= 16)
-        got = bm25_select_f32<16>(sc, m, k, lo, lane, scratch, tk.buf);
-      else if (nv <= 20)
-        got = bm25_select_f32<20>(sc, m, k, lo, lane, scratch, tk.buf);
-      else
-        got = bm25_select_f32<32>(sc, m, k, lo, lane, scratch, tk.buf);
-      wave_lds_fence();
-    }
-    if (got >= 0) {
-    } else if (nv <= 4)
-      got = bm25_argmax_rounds<4>(sc, m, k, lo, lane, tk.buf);
-    else if (nv <= 8)
-      got = bm25_argmax_rounds<8>(sc, m, k, lo, lane, tk.buf);
-    else if (nv <= 10)
-      got = bm25_argmax_rounds<10>(sc, m, k, lo, lane, tk.buf);
-    else if (nv <= 12)
-      got = bm25_argmax_rounds<12>(sc, m, k, lo, lane, tk.buf);
-    else if (nv <= 16)
-      got = bm25_argmax_rounds<16>(sc, m, k, lo, lane, tk.buf);
-    else if (nv <= 20)
-      got = bm25_argmax_rounds<20>(sc, m, k, lo, lane, tk.buf);
-    else if (nv <= 24)
-      got = bm25_argmax_rounds<24>(sc, m, k, lo, lane, tk.buf);
-    else
-      got = bm25_argmax_rounds<32>(sc, m, k, lo, lane, tk.buf);
-    wave_lds_fence();
+    C32* scratch = reinterpret_cast<C32*>(tk_ps);  // 64 x 8 B each: the token table is dead once the slab is scored
+    double* xs = reinterpret_cast<double*>(tk_pe);
+    const int got = bm25_rank_slab<NVT>(sc, m, k, lo, lane, use_select != 0, scratch, xs, tk.buf);
     tk.cnt = got;
     done = true;
   }
@@ -482,9 +550,18 @@ int bm_run(amdr_bm25* h, int ws, const int* q_terms_dev, const long long* q_ptr_
   if (p.lds > 48 * 1024) {  // never with the slab limits of bm_plan (4 096 x 8 B + lists < 48 KiB); guard for edits
     return fail(AMDR_EINVAL, "bm25: slab needs %zu B of LDS", p.lds);
   }
-  hipLaunchKernelGGL(bm25_score_topk_kernel<1>, dim3(p.nslabs, nq), dim3(64), p.lds, st, h->term_ptr, h->post_doc,
-                     h->post_w, h->idf, (long)h->n_terms, (long)h->n_docs, q_terms_dev, q_ptr_dev, nq, k, p.cap,
-                     p.slab, bm_select_enabled() ? 1 : 0, full_dev, part, fs, fi);
+#define AMDR_BM_LAUNCH(NVT)                                                                                          \
+  hipLaunchKernelGGL((bm25_score_topk_kernel<1, NVT>), dim3(p.nslabs, nq), dim3(64), p.lds, st, h->term_ptr,         \
+                     h->post_doc, h->post_w, h->idf, (long)h->n_terms, (long)h->n_docs, q_terms_dev, q_ptr_dev, nq, k, \
+                     p.cap, p.slab, bm_select_enabled() ? 1 : 0, full_dev, part, fs, fi)
+  const int nv = bm_use_argmax(k, p.slab) ? (p.slab + 63) / 64 : 1;  // the staged selector needs no register bucket
+  if (nv <= 4) AMDR_BM_LAUNCH(4);
+  else if (nv <= 8) AMDR_BM_LAUNCH(8);
+  else if (nv <= 10) AMDR_BM_LAUNCH(10);
+  else if (nv <= 16) AMDR_BM_LAUNCH(16);
+  else if (nv <= 20) AMDR_BM_LAUNCH(20);
+  else AMDR_BM_LAUNCH(32);
+#undef AMDR_BM_LAUNCH
   AMDR_HIP(hipGetLastError());
   if (scores_dev && !direct) {
     size_t lds = (size_t)kBmWaves * p.cap_merge * sizeof(C64) + kBmWaves * sizeof(int);

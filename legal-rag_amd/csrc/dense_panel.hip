@@ -157,7 +157,7 @@ __device__ __forceinline__ void panel_tile(const float* __restrict__ X, long n, 
 
 constexpr int panel_nbe(int nb, int waves) { return (2 * nb + waves - 1) / waves * waves / 2; }
 
-// grid: 1-D, m_tiles x parts blocks.  Part p covers `base` (+1 for p < rem) row blocks of 16.
+// grid: 1-D, m_tiles x parts LOGICAL blocks.  Part p covers `base` (+1 for p < rem) row blocks of 16.
 // Logical order (after the XCD remap): groups of `gm` query tiles; inside a group part-major,
 // so that the blocks sharing a panel are neighbours on one XCD and a group's query tiles stay
 // in that XCD's L2 while its parts go by.
@@ -169,26 +169,34 @@ __global__ __launch_bounds__(WAVES * 64) void dense_panel_scores_kernel(const fl
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  int part, mt;
-  {
-    const int nwg = m_tiles * parts, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int per_group = gm * parts;
-    const int g = logical / per_group, rr = logical - g * per_group;
-    int gsz = m_tiles - g * gm;
-    if (gsz > gm) gsz = gm;
-    part = rr / gsz;
-    mt = g * gm + (rr - part * gsz);
+  // A block walks the logical blocks bid = blockIdx.x, + gridDim.x, ... (the host launches either
+  // one block per logical block or, persistent form, as many as stay resident; gridDim.x % 8 == 0
+  // there, so bid & 7 is still the XCD the block runs on).  The last barrier of a tile is behind
+  // every wave's last fragment read, so the next tile's first DMA may overwrite the buffers.
+  // (Tried: the tiles of a block as ONE chunk stream — the next tile's first chunk issued in place
+  // of "chunk nch", so that it lands during the last MFMAs and the epilogue: +- 0 at every shape.)
+  const int nwg = m_tiles * parts;
+  for (int bid = blockIdx.x; bid < nwg; bid += gridDim.x) {
+    int part, mt;
+    {
+      const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+      const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+      const int per_group = gm * parts;
+      const int g = logical / per_group, rr = logical - g * per_group;
+      int gsz = m_tiles - g * gm;
+      if (gsz > gm) gsz = gm;
+      part = rr / gsz;
+      mt = g * gm + (rr - part * gsz);
+    }
+    const int nbp = base + (part < rem ? 1 : 0);
+    const long row0 = 16L * ((long)part * base + (part < rem ? part : rem));
+    const int q0w = (mt * WAVES + wave) * 32;
+    constexpr int NBE = panel_nbe(NB, WAVES);
+    if (nbp == NB)
+      panel_tile<NB, NBE, WAVES>(X, n, Q, nq, d, row0, q0w, ldS, S, smem, lane, wave);
+    else if (NB > 1)
+      panel_tile<(NB > 1 ? NB - 1 : 1), NBE, WAVES>(X, n, Q, nq, d, row0, q0w, ldS, S, smem, lane, wave);
   }
-  const int nbp = base + (part < rem ? 1 : 0);
-  const long row0 = 16L * ((long)part * base + (part < rem ? part : rem));
-  const int q0w = (mt * WAVES + wave) * 32;
-  constexpr int NBE = panel_nbe(NB, WAVES);
-  if (nbp == NB)
-    panel_tile<NB, NBE, WAVES>(X, n, Q, nq, d, row0, q0w, ldS, S, smem, lane, wave);
-  else if (NB > 1)
-    panel_tile<(NB > 1 ? NB - 1 : 1), NBE, WAVES>(X, n, Q, nq, d, row0, q0w, ldS, S, smem, lane, wave);
 }
 
 constexpr int kPanelWaves = 4;
@@ -253,7 +261,23 @@ static int launch_panel(const DensePanelPlan& p, const float* X, long n, int d, 
   // > 64 KiB of dynamic LDS needs the opt-in; it is a per-device function attribute, cheap to set
   AMDR_HIP(hipFuncSetAttribute((const void*)dense_panel_scores_kernel<NB, kPanelWaves>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel_lds(NB, kPanelWaves)));
-  hipLaunchKernelGGL((dense_panel_scores_kernel<NB, kPanelWaves>), dim3(p.m_tiles * p.parts),
+  // Persistent grid: as many blocks as stay resident at once (occupancy x CUs, a multiple of 8 so that a
+  // block's logical ids keep its XCD), each walking its share of the logical blocks — no block is launched
+  // into the LDS a retiring one frees, and the tile loop runs on without a dispatch in between (UCC-en step:
+  // 280 -> 268 us; other shapes + 0.5-1.2 %).  AMDR_PANEL_PERSIST=0 launches one block per logical block.
+  int grid = p.m_tiles * p.parts;
+  const char* pe = getenv("AMDR_PANEL_PERSIST");
+  if (!(pe && pe[0] == '0')) {
+    int dev = 0, cus = 0, per_cu = 0;
+    AMDR_HIP(hipGetDevice(&dev));
+    AMDR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    AMDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dense_panel_scores_kernel<NB, kPanelWaves>,
+                                                          kPanelWaves * 64, p.lds));
+    if (pe && atoi(pe) >= 1) per_cu = atoi(pe);
+    const int resident = per_cu * cus / 8 * 8;
+    if (resident >= 8 && grid > resident) grid = resident;
+  }
+  hipLaunchKernelGGL((dense_panel_scores_kernel<NB, kPanelWaves>), dim3(grid),
                      dim3(kPanelWaves * 64), p.lds, st, X, n, Q, nq, d, p.parts, p.base, p.rem, p.m_tiles, p.gm, ldS, S);
   AMDR_HIP(hipGetLastError());
   return AMDR_OK;

@@ -4,6 +4,7 @@
     AMDR_DENSE_PANEL=0        32x32 wave tiles (dense_mfma.hip)
     AMDR_DENSE_PANEL=1        panel kernel (dense_panel.hip), planner's choice of parts
     AMDR_PANEL_PARTS=<p>      panel kernel with the row blocks cut into p parts
+    AMDR_PANEL_PERSIST=0      one block per logical block instead of the persistent grid
 Prints the median / min time of the scores kernel (handle profiling events) per variant and the
 fp32 TFLOP/s it corresponds to, and checks every variant's top-k against torch fp32.
 
@@ -43,7 +44,8 @@ def main():
     idx.reserve(nq, k)
     nb = (n + 15) // 16
     pmin = (nb + 7) // 8
-    variants = [("tile32", {"AMDR_DENSE_PANEL": "0"}), ("panel", {"AMDR_DENSE_PANEL": "1"})]
+    variants = [("tile32", {"AMDR_DENSE_PANEL": "0"}), ("panel", {"AMDR_DENSE_PANEL": "1"}),
+                ("panel/1 per block", {"AMDR_DENSE_PANEL": "1", "AMDR_PANEL_PERSIST": "0"})]
     for qb in ("0",):
         for p in sorted(set([pmin, pmin + 1, pmin + 2, pmin + 3, pmin + 4, (nb + 4) // 5, (nb + 3) // 4, (nb + 2) // 3])):
             if pmin <= p <= nb:
@@ -54,7 +56,7 @@ def main():
     agree = {}
     for r in range(rounds + 1):
         for name, env in variants:
-            for kk in ("AMDR_DENSE_PANEL", "AMDR_PANEL_PARTS"):
+            for kk in ("AMDR_DENSE_PANEL", "AMDR_PANEL_PARTS", "AMDR_PANEL_PERSIST"):
                 os.environ.pop(kk, None)
             os.environ.update(env)
             steps = 5
@@ -74,7 +76,7 @@ def main():
     for name, _ in variants:
         t = sorted(times[name])
         med, mn = t[len(t) // 2], t[0]
-        print(f"  {name:16s} median {med * 1e3:8.1f} us  min {mn * 1e3:8.1f} us  {flops / (med * 1e-3) / 1e12:6.1f} TFLOP/s "
+        print(f"  {name:18s} median {med * 1e3:8.1f} us  min {mn * 1e3:8.1f} us  {flops / (med * 1e-3) / 1e12:6.1f} TFLOP/s "
               f"({flops / (med * 1e-3) / 1e12 / 157.3:.3f} of fp32 MFMA peak)  id agreement {agree[name]:.4f}")
     idx.close()
 

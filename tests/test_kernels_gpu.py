@@ -293,7 +293,7 @@ def bm25_pair(nat, docs):
 
 @pytest.mark.parametrize("n_docs,vocab,max_len,k", [
     (591, 3926, 400, 10), (591, 3926, 400, 80), (12, 30, 8, 10), (5000, 500, 60, 10), (9000, 2000, 40, 256),
-    (1, 5, 5, 3),
+    (1, 5, 5, 3), (1260, 1181, 200, 10), (2048, 900, 30, 40), (2049, 900, 30, 10),
 ])
 def test_bm25_bit_exact(nat, n_docs, vocab, max_len, k):
     from oracle import bm25 as OB
@@ -361,6 +361,36 @@ def test_bm25_select_and_exact_rounds_agree(nat, monkeypatch):
         out[flag] = [gi.search(queries, k) for k in (1, 10, 16, 40)]
     for a, b in zip(out["1"], out["0"]):
         assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
+
+
+def test_bm25_mass_ties_at_the_cut(nat, monkeypatch):
+    """More than 64 documents tie AT the k-th score: blocks of identical documents (equal non-zero fp64 scores),
+    untouched documents at +0.0, and common-term (negative idf) documents below zero.  The fp32-image ranking
+    takes everything above the cut plus the lowest ids of the tie (bm25_select_f32), the exact rounds are
+    pinned by AMDR_BM25_SELECT=0; both must give the oracle's order."""
+    from oracle import bm25 as OB
+    docs = []
+    for i in range(600):
+        if i % 3 == 0:
+            docs.append(["alpha", "beta"])            # 200 identical documents
+        elif i % 3 == 1:
+            docs.append(["gamma"] * (1 + i % 2))       # two more tie classes
+        else:
+            docs.append(["common", f"u{i}"])
+    docs[17] = ["alpha", "alpha", "delta"]
+    docs[401] = ["delta", "common"]
+    ob, csr, gi = bm25_pair(nat, docs)
+    queries = [["alpha"], ["alpha", "delta"], ["gamma"], ["common"], ["common", "alpha"], ["delta"], ["nothing"],
+               ["u2", "u5", "alpha"], ["beta", "gamma", "common", "delta"]]
+    tid = [[csr["vocab"].get(t, -1) for t in q] for q in queries]
+    for flag in ("1", "0"):
+        monkeypatch.setenv("AMDR_BM25_SELECT", flag)
+        for k in (1, 10, 16, 64, 80):
+            s, i = gi.search(tid, k)
+            for qn, q in enumerate(queries):
+                exp = OB.search(ob, q, k)
+                assert i[qn].tolist() == [e[0] for e in exp], (flag, k, q)
+                assert s[qn].tolist() == [e[1] for e in exp], (flag, k, q)
 
 
 def test_bm25_toy_golden(nat):
