@@ -110,7 +110,12 @@ def _finalseg_cut(buf: str) -> List[str]:
     return out
 
 
+_ASCII_DICT_MARKS = frozenset("&+#")  # every entry of _ASCII_DICT_WORDS holds one of these
+
+
 def _cut_block(blk: str) -> List[str]:
+    if _ASCII_DICT_MARKS.isdisjoint(blk):  # no dictionary word can start anywhere in the block
+        return [blk] if len(blk) == 1 else _finalseg_cut(blk)
     out: List[str] = []
     buf = ""
     i = 0
