@@ -77,15 +77,18 @@ def test_merge_f64_ties_prefer_lower_global_id(big):
     assert mi.tolist() == [[7, 40, 8, 41]] and ms.tolist() == [[3.0, 3.0, 2.0, 1.0]]
 
 
-def test_device_api_is_graph_capturable():
+@pytest.mark.parametrize("nq", [64, 16384])
+def test_device_api_is_graph_capturable(nq):
     """include/amdretrieval.h: "_device" entry points enqueue only, and after reserve() they
-    allocate nothing — so a whole hybrid step can be captured into a hipGraph and replayed."""
+    allocate nothing — so a whole hybrid step can be captured into a hipGraph and replayed.
+    64 queries: the tile kernel; 16 384: the panel kernel on its persistent grid (more logical
+    blocks than stay resident; its launch asks the runtime for occupancy and CU count)."""
     import torch
     from legal_rag_amd import _native
     from legal_rag_amd.retrieval.engine import HybridEngine
     from oracle import bm25 as OB
     rng = np.random.default_rng(1)
-    n, d, nq, k = 600, 768, 64, 10
+    n, d, k = 600, 768, 10
     X = rng.standard_normal((n, d)).astype(np.float32)
     X /= np.linalg.norm(X, axis=1, keepdims=True)
     words = [f"w{i}" for i in range(200)]
