@@ -128,6 +128,30 @@ def test_dense_panel_kernel_shapes(nat, parts, monkeypatch):
         check_dense(nat, unit_rows(rng, n, d), unit_rows(rng, nq, d), k)
 
 
+def test_dense_panel_persistent_grid_equals_one_block_per_tile(nat, monkeypatch):
+    """More logical blocks than stay resident (dense_panel.hip launches occupancy x CUs persistent blocks that
+    walk them): ragged last query tile, parts of unequal size, a grid that is not a multiple of the resident
+    count; AMDR_PANEL_PERSIST=0 pins one block per logical block, =1 forces one resident block per CU (a longer
+    walk).  Identical bits in all three, and the oracle's answer."""
+    rng = np.random.default_rng(81)
+    X, Q = unit_rows(rng, 591, 768), unit_rows(rng, 20011, 768)
+    out = {}
+    for flag in (None, "0", "1"):
+        if flag is None:
+            monkeypatch.delenv("AMDR_PANEL_PERSIST", raising=False)
+        else:
+            monkeypatch.setenv("AMDR_PANEL_PERSIST", flag)
+        idx = nat.DenseIndex(X)
+        out[flag] = idx.search(Q, 10)
+        idx.close()
+    for flag in ("0", "1"):
+        assert np.array_equal(out[None][1], out[flag][1]) and np.array_equal(out[None][0], out[flag][0])
+    monkeypatch.delenv("AMDR_PANEL_PERSIST", raising=False)
+    sel = np.concatenate([np.arange(0, 300), np.arange(19800, 20011)])
+    s, i = check_dense(nat, X, Q[sel], 10)
+    assert np.array_equal(i, out[None][1][sel])
+
+
 def test_dense_panel_agrees_bitwise_with_tiles(nat, monkeypatch):
     """The panel kernel and the 32x32-tile kernel feed the matrix pipe the same k order per
     (query, row): identical bits, identical ids."""
