@@ -361,7 +361,6 @@ template <int V>
 __device__ __forceinline__ int select_row_pair(const float* __restrict__ S, long ldS, long n, int q, bool has_q, int k,
                                                int lane, C32* scratch, C32& out) {
   static_assert(V % 4 == 0, "four consecutive scores per 16-byte load");
-  C32 keys[V];
   const float* row = S + (size_t)q * ldS;
   const int j = lane & 31;
   // 16-byte loads (a half-wave covers 512 B of its row per instruction): the kernel waits on memory
@@ -374,14 +373,15 @@ __device__ __forceinline__ int select_row_pair(const float* __restrict__ S, long
     const v4f z = {0.f, 0.f, 0.f, 0.f};
     blk[u] = (has_q && c0 < ldS) ? __builtin_nontemporal_load(reinterpret_cast<const v4f*>(row + c0)) : z;  // read once
   }
+  u32 sk[V];  // score keys only; ids (128 u + 4 j + e) are attached to the survivors (wave_select_small_pair32)
 #pragma unroll
   for (int u = 0; u < V / 4; ++u)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const long r = 128L * u + 4 * j + e;
-      keys[4 * u + e] = (has_q && r < n) ? C32::make(blk[u][e], (u32)r) : C32::pad();
+      sk[4 * u + e] = (has_q && r < n) ? ord32(blk[u][e]) : 0u;
     }
-  return wave_select_small_pair<C32, V>(keys, k, scratch, lane, out);
+  return wave_select_small_pair32<V>(sk, [&](int v) { return 128 * (v >> 2) + 4 * j + (v & 3); }, k, scratch, lane, out);
 }
 
 __global__ __launch_bounds__(64) void scores_pair_topk_kernel(const float* __restrict__ S, long ldS, long n, int nq,

@@ -359,6 +359,18 @@ __device__ __forceinline__ int wave_allmin_i32(int x) {
   return x;
 }
 
+// K32: a bare 32-bit ordered score key (ord32; 0 = no candidate) for the steps of a selection that do not need
+// the id yet: one register, one exchange and one compare per step instead of two / two / three.
+struct K32 {
+  u32 c;
+};
+__device__ __forceinline__ bool better(const K32& a, const K32& b) { return a.c > b.c; }
+__device__ __forceinline__ K32 wave_xchg_xor(const K32& v, int s) {
+  K32 o;
+  o.c = lane_xor_sw(v.c, s);
+  return o;
+}
+
 // Bitonic network across the lanes: sorts every aligned group of N lanes (N = 16, 32 or 64)
 // descending; exchange steps never reach past the group.  (The last merge runs in the same
 // direction in EVERY group: with the textbook alternation the odd groups would come out ascending.)
@@ -423,37 +435,46 @@ __device__ inline int wave_select_small(const C (&keys)[V], int k, C* scratch /*
 // k <= 32.  Returns the survivors of THIS lane's half (min(cnt, k) of them are valid results, best
 // first, in lanes 0..k-1 of the half: `out`), or -1 for the whole wave if either half had more
 // than 32 survivors (mass ties at the cut) — the caller then ranks both by the general path.
-template <class C, int V>
-__device__ inline int wave_select_small_pair(const C (&keys)[V], int k, C* scratch /* LDS, 64 entries */, int lane,
-                                             C& out) {
-  C lbest = C::pad();
+// Implementation on 32-bit score keys (the first version carried 64-bit (score, ~id) keys through every step:
+// 29.0 -> 27.6 us per 37 376 UCC-en queries): the lane best, the sort of the 32 lane bests and the cut look at
+// the score only (v_max_u32 / one exchange + one compare per stage); the 64-bit (score, ~id) candidates are built
+// for the survivors alone — every key whose SCORE reaches the cut takes part, so equal scores at the cut are all
+// there and the final 64-bit sort puts the lower id first, exactly as the 64-bit selector does.
+// sk[v]: ord32 of the score, 0 for "no candidate"; id_of(v): the candidate's id.
+template <int V, class IdOf>
+__device__ inline int wave_select_small_pair32(const u32 (&sk)[V], IdOf&& id_of, int k, C32* scratch /* LDS, 64 */,
+                                               int lane, C32& out) {
+  K32 lb;
+  lb.c = 0u;
 #pragma unroll
-  for (int v = 0; v < V; ++v)
-    if (better(keys[v], lbest)) lbest = keys[v];
-  const C sorted_best = wave_sortN_desc<C, 32>(lbest, lane);
+  for (int v = 0; v < V; ++v) lb.c = sk[v] > lb.c ? sk[v] : lb.c;
+  const K32 sorted_best = wave_sortN_desc<K32, 32>(lb, lane);
   const int src = (lane & 32) + (k - 1 < 31 ? k - 1 : 31);  // k-th lane best of this half
-  C T;
-  T.c = ((u64)(u32)__shfl((int)(u32)(sorted_best.c >> 32), src) << 32) | (u32)__shfl((int)(u32)sorted_best.c, src);
+  const u32 T = (u32)__shfl((int)sorted_best.c, src);
   const bool upper = lane >= 32;
   int cnt = 0;
 #pragma unroll
   for (int v = 0; v < V; ++v) {
-    const bool pass = !keys[v].is_pad() && !better(T, keys[v]);
+    const bool pass = sk[v] != 0u && sk[v] >= T;
     const u64 m = __ballot(pass);
     const u32 mlo = (u32)m, mhi = (u32)(m >> 32);
     const int nlo = __popc(mlo), nhi = __popc(mhi);
     const int tot = upper ? nhi : nlo;
     if (__ballot(cnt + tot > 32)) return -1;
     const int below = (int)__builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u)) - (upper ? nlo : 0);
-    if (pass) scratch[(lane & 32) + cnt + below] = keys[v];
+    if (pass) {
+      C32 c;
+      c.c = ((u64)sk[v] << 32) | (u64)(0xffffffffu - (u32)id_of(v));
+      scratch[(lane & 32) + cnt + below] = c;
+    }
     cnt += tot;
   }
   wave_lds_fence();
-  C c = ((lane & 31) < cnt) ? scratch[lane] : C::pad();
+  C32 c = ((lane & 31) < cnt) ? scratch[lane] : C32::pad();
   if (__ballot((lane & 31) >= 16 && (lane & 31) < cnt) == 0ull)
-    c = wave_sortN_desc<C, 16>(c, lane);
+    c = wave_sortN_desc<C32, 16>(c, lane);
   else
-    c = wave_sortN_desc<C, 32>(c, lane);
+    c = wave_sortN_desc<C32, 32>(c, lane);
   wave_lds_fence();
   out = c;
   return cnt;
