@@ -31,6 +31,7 @@ constexpr int kBmArgmaxK = 96;  // deepest k ever ranked by arg-max rounds (one 
 __host__ __device__ inline bool bm_use_argmax(int k, int slab) {
   return slab <= 2048 && (k <= 16 || (k <= kBmArgmaxK && k * ((slab + 63) >> 6) <= 480));
 }
+constexpr int kBmTok = 32;  // query tokens resolved per group (lanes fetch them in parallel)
 constexpr int kBmOneWaveDocs = 2048;  // slabs up to this size are scored and ranked by ONE wave (<= 32 scores per lane)
 
 __device__ __forceinline__ long uniform_i64(long v) {  // value known to be the same in every lane -> scalar pair
@@ -276,10 +277,13 @@ __global__ __launch_bounds__(WAVES * 64) void bm25_score_topk_kernel(
   double* sc = reinterpret_cast<double*>(smem);
   C64* lists = reinterpret_cast<C64*>(sc + slab);
   int* cnts = reinterpret_cast<int*>(lists + (size_t)WAVES * cap);
-  long* tk_ps = reinterpret_cast<long*>(cnts + 4);  // [64] posting range + idf of up to 64 query tokens
-  long* tk_pe = tk_ps + 64;
-  double* tk_w = reinterpret_cast<double*>(tk_pe + 64);
-  int* tk_n = reinterpret_cast<int*>(tk_w + 64);  // tokens of the current group that have postings in this slab
+  // Token table: posting range + idf of up to kBmTok query tokens at a time (32: a UCC-en query has 19 tokens; the
+  // 1 KiB region is reused by the ranking — 64 survivor keys + 64 exact scores — and a 64-token table made it
+  // 1.5 KiB: 25 -> 27 resident waves per CU at UCC-en size).
+  long* tk_ps = reinterpret_cast<long*>(cnts + 4);
+  long* tk_pe = tk_ps + kBmTok;
+  double* tk_w = reinterpret_cast<double*>(tk_pe + kBmTok);
+  int* tk_n = reinterpret_cast<int*>(tk_ps + 128);  // tokens of the current group that have postings in this slab
   constexpr int NT = WAVES * 64;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -293,12 +297,12 @@ __global__ __launch_bounds__(WAVES * 64) void bm25_score_topk_kernel(
   block_sync<WAVES>();
 
   // Token metadata (posting range inside this slab, idf) is fetched by the lanes IN PARALLEL,
-  // 64 tokens at a time, and parked in LDS: walking the tokens one by one would chain three
+  // kBmTok tokens at a time, and parked in LDS: walking the tokens one by one would chain three
   // dependent global loads (term id -> term_ptr -> postings) per token, ~1.5 us each.
   int nt_total = 0;  // block-uniform
   const long t0 = q_ptr[qi], t1 = q_ptr[qi + 1];
-  for (long tb = t0; tb < t1; tb += 64) {
-    const int nt_all = (int)((t1 - tb) < 64 ? (t1 - tb) : 64);
+  for (long tb = t0; tb < t1; tb += kBmTok) {
+    const int nt_all = (int)((t1 - tb) < kBmTok ? (t1 - tb) : kBmTok);
     if (tid < 64) {
       long ps = 0, pe = 0;
       double w = 0.0;
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(WAVES * 64) void bm25_score_topk_kernel(
   bool done = false;
   if (WAVES == 1 && bm_use_argmax(k, slab)) {
     C32* scratch = reinterpret_cast<C32*>(tk_ps);  // 64 x 8 B each: the token table is dead once the slab is scored
-    double* xs = reinterpret_cast<double*>(tk_pe);
+    double* xs = reinterpret_cast<double*>(tk_ps + 64);
     const int got = bm25_rank_slab<NVT>(sc, m, k, lo, lane, use_select != 0, scratch, xs, tk.buf);
     tk.cnt = got;
     done = true;
@@ -523,7 +527,7 @@ void bm_plan(int64_t n_docs, int nq, int k, BmPlan* p) {
   p->cap_merge = topk_cap(k);
   p->cap = argmax ? (k <= 16 ? 16 : kBmArgmaxK) : p->cap_merge;
   p->lds = (size_t)p->slab * sizeof(double) + (size_t)p->waves * p->cap * sizeof(C64) + 4 * sizeof(int) +
-           64 * (2 * sizeof(long) + sizeof(double)) + 8;
+           128 * sizeof(long) + 8;  // token table (3 x kBmTok x 8 B) / ranking scratch (2 x 64 x 8 B)
   p->part_bytes = (size_t)p->nslabs * nq * k * sizeof(C64);
 }
 

@@ -332,6 +332,8 @@ def test_bm25_bit_exact(nat, n_docs, vocab, max_len, k):
             toks += [toks[0], "UNKNOWN", toks[-1]]  # duplicates + out-of-vocabulary
         queries.append(toks)
     queries.append([])
+    queries.append([words[j] for j in rng.integers(0, min(vocab, 60), size=100)] + ["UNKNOWN"] * 3)  # several token groups
+    queries.append(["UNKNOWN"] * 40 + [words[0]])  # a first group without any known token
     tid = [[csr["vocab"].get(t, -1) for t in q] for q in queries]
     full = gi.get_scores(tid)
     s, i = gi.search(tid, k)
