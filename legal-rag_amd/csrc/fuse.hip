@@ -313,15 +313,16 @@ __global__ __launch_bounds__(64) void fuse_packed_kernel(amdr_fuse_params_t P, C
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const int j = sl;
-    bool has = live && j < ch[c].k;
+    const bool inr = live && j < ch[c].k;
     long long id = -1;
-    if (has) id = ch[c].ids[(size_t)qi * ch[c].k + j];
-    has = has && id >= 0;
     double s = 0.0;
-    if (has) {
+    if (inr) {  // id and score are requested together: one memory round trip, not two
+      id = ch[c].ids[(size_t)qi * ch[c].k + j];
       s = chan_score(ch[c], qi, j);
-      if (ch[c].row2uid) id = ch[c].row2uid[id];
     }
+    const bool has = inr && id >= 0;
+    if (!has) s = 0.0;
+    if (has && ch[c].row2uid) id = ch[c].row2uid[id];
     my_uid[c] = has ? id : -1;
     s_chs[seg][c][sl] = s;
     n[c] = seg_allsum_i32<W>(has ? 1 : 0);
