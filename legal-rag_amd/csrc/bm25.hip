@@ -384,11 +384,21 @@ __global__ __launch_bounds__(WAVES * 64) void bm25_score_topk_kernel(
           }
         }
       }
+      // One wave: the update is an LDS fp64 atomic add without return (ds_add_f64: the same correctly rounded
+      // add, no read-back to wait for); the LDS unit serves a wave's operations in order, so chunk u + 1 — possibly
+      // the next token hitting the same document — lands after chunk u.  (As ds_read / v_add_f64 / ds_write with a
+      // fence per chunk the scatter was a chain of LDS round trips.)
 #pragma unroll
       for (int u = 0; u < kAhead; ++u) {
-        if (ok[u]) sc[dd[u] - lo] += wv[u] * ww[u];
-        block_sync<WAVES>();
+        if (WAVES == 1) {
+          if (ok[u])
+            __hip_atomic_fetch_add(&sc[dd[u] - lo], wv[u] * ww[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        } else {
+          if (ok[u]) sc[dd[u] - lo] += wv[u] * ww[u];
+          block_sync<WAVES>();
+        }
       }
+      if (WAVES == 1) wave_lds_fence();
     }
   }
 
