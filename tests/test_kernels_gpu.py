@@ -419,6 +419,26 @@ def test_bm25_mass_ties_at_the_cut(nat, monkeypatch):
                 assert s[qn].tolist() == [e[1] for e in exp], (flag, k, q)
 
 
+def test_bm25_denormal_products_and_sums(nat):
+    """The scatter adds with an LDS fp64 atomic (ds_add_f64): subnormal products, subnormal sums and sums that
+    cross into the normal range must come out as numpy's fp64 gives them (no flush to zero)."""
+    n, V = 100, 8
+    term_ptr = np.arange(0, (V + 1) * n, n, dtype=np.int64)
+    post_doc = np.tile(np.arange(n, dtype=np.int32), V)
+    post_tf = np.ones(n * V, dtype=np.int32)
+    doc_len = np.full(n, V, dtype=np.int32)
+    idf = np.array([3e-310, -1e-310, 5e-324, 2.5e-308, -2.4e-308, 1e-309, 7e-311, 4e-320], dtype=np.float64)
+    gi = nat.BM25Index(term_ptr, post_doc, post_tf, idf, doc_len, float(V), 1.5, 0.75)
+    queries = [[0, 1, 2], [3, 4], [5, 6, 7, 2, 2], [3, 4, 0, 1], [3, 3, 3]]
+    full = gi.get_scores(queries)
+    w = np.float64(1.0) * (1.5 + 1) / (np.float64(1.0) + 1.5 * (1 - 0.75 + 0.75 * np.float64(V) / np.float64(V)))
+    for q, row in zip(queries, full):
+        s = np.float64(0.0)
+        for t in q:
+            s = s + idf[t] * w
+        assert row.tolist() == [float(s)] * n
+
+
 def test_bm25_toy_golden(nat):
     g = load_golden("bm25_toy.json")
     from oracle import bm25 as OB
