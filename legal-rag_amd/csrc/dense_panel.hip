@@ -268,11 +268,20 @@ static int launch_panel(const DensePanelPlan& p, const float* X, long n, int d, 
   int grid = p.m_tiles * p.parts;
   const char* pe = getenv("AMDR_PANEL_PERSIST");
   if (!(pe && pe[0] == '0')) {
+    // (device, NB) -> resident blocks per CU x CUs, asked once per process and device (a benign race writes the
+    // same value twice)
+    static int resident_cache[64] = {0};
     int dev = 0, cus = 0, per_cu = 0;
     AMDR_HIP(hipGetDevice(&dev));
-    AMDR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    AMDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dense_panel_scores_kernel<NB, kPanelWaves>,
-                                                          kPanelWaves * 64, p.lds));
+    const int slot = dev & 63;
+    if (resident_cache[slot] == 0) {
+      AMDR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+      AMDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dense_panel_scores_kernel<NB, kPanelWaves>,
+                                                            kPanelWaves * 64, p.lds));
+      resident_cache[slot] = (per_cu << 16) | (cus & 0xffff);
+    }
+    per_cu = resident_cache[slot] >> 16;
+    cus = resident_cache[slot] & 0xffff;
     if (pe && atoi(pe) >= 1) per_cu = atoi(pe);
     const int resident = per_cu * cus / 8 * 8;
     if (resident >= 8 && grid > resident) grid = resident;
