@@ -451,23 +451,32 @@ __device__ inline int wave_select_small_pair32(const u32 (&sk)[V], IdOf&& id_of,
   const K32 sorted_best = wave_sortN_desc<K32, 32>(lb, lane);
   const int src = (lane & 32) + (k - 1 < 31 ? k - 1 : 31);  // k-th lane best of this half
   const u32 T = (u32)__shfl((int)sorted_best.c, src);
-  const bool upper = lane >= 32;
-  int cnt = 0;
+  // Survivors -> scratch: every lane counts its own (one compare + add per key), an inclusive prefix sum over the
+  // 32 lanes of the half gives each lane its first slot, then the lane stores its survivors one after the other
+  // (their order in the scratch does not matter: they are sorted next).  The first version ran a ballot, two
+  // popcounts, two mbcnt and an overflow vote PER KEY REGISTER (~12 vector instructions x V against ~6 here; the
+  // kernel is exactly vector-issue-bound).
+  const u32 Te = T > 1u ? T : 1u;  // "not a candidate" is key 0
+  int mine = 0;
+#pragma unroll
+  for (int v = 0; v < V; ++v) mine += (sk[v] >= Te) ? 1 : 0;
+  int incl = mine;
+  const int sl = lane & 31;
+#pragma unroll
+  for (int s = 1; s < 32; s <<= 1) {
+    const int o = __shfl_up(incl, s, 32);
+    incl += (sl >= s) ? o : 0;
+  }
+  const int cnt = __shfl(incl, (lane & 32) + 31);  // survivors of this lane's half
+  if (__ballot(cnt > 32)) return -1;
+  int at = (lane & 32) + incl - mine;
 #pragma unroll
   for (int v = 0; v < V; ++v) {
-    const bool pass = sk[v] != 0u && sk[v] >= T;
-    const u64 m = __ballot(pass);
-    const u32 mlo = (u32)m, mhi = (u32)(m >> 32);
-    const int nlo = __popc(mlo), nhi = __popc(mhi);
-    const int tot = upper ? nhi : nlo;
-    if (__ballot(cnt + tot > 32)) return -1;
-    const int below = (int)__builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u)) - (upper ? nlo : 0);
-    if (pass) {
+    if (sk[v] >= Te) {
       C32 c;
       c.c = ((u64)sk[v] << 32) | (u64)(0xffffffffu - (u32)id_of(v));
-      scratch[(lane & 32) + cnt + below] = c;
+      scratch[at++] = c;
     }
-    cnt += tot;
   }
   wave_lds_fence();
   C32 c = ((lane & 31) < cnt) ? scratch[lane] : C32::pad();
