@@ -136,23 +136,31 @@ __device__ __forceinline__ int bm25_select_f32(const double* sc, int m, int k, l
   }
   // Survivors: key = image | ~document (16 bits: a slab has <= 2 048) | slot; the slot finds the
   // survivor's exact fp64 score (parked beside the key) again after the sort.
-  int cnt = 0;
-  bool overflow = false;
+  // (each lane counts its own survivors, one inclusive prefix sum over the wave hands out the slots: ~5 vector
+  // instructions per score register instead of a ballot / popcount / mbcnt round per register)
+  const u32 Te = T > 1u ? T : 1u;
+  int mine = 0;
 #pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    const bool pass = img[v] != 0u && img[v] >= T;
-    const u64 mk = __ballot(pass);
-    const int tot = __popcll(mk);
-    overflow = overflow || cnt + tot > 64;
-    if (!overflow) {
-      if (pass) {
-        const int at = cnt + (int)__builtin_amdgcn_mbcnt_hi((u32)(mk >> 32), __builtin_amdgcn_mbcnt_lo((u32)mk, 0u));
+  for (int v = 0; v < NV; ++v) mine += (img[v] >= Te) ? 1 : 0;
+  int incl = mine;
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) {
+    const int o = __shfl_up(incl, s);
+    incl += (lane >= s) ? o : 0;
+  }
+  int cnt = __builtin_amdgcn_readlane(incl, 63);
+  const bool overflow = cnt > 64;
+  if (!overflow) {
+    int at = incl - mine;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      if (img[v] >= Te) {
         C32 c;
         c.c = ((u64)img[v] << 32) | (u64)(((0xffffu - (u32)(lane + 64 * v)) << 8) | (u32)at);
         scratch[at] = c;
         xs[at] = bm25_ranked(sc[lane + 64 * v]);
+        ++at;
       }
-      cnt += tot;
     }
   }
   if (overflow) {
