@@ -12,15 +12,15 @@
 // rate as the vector ALU, but the accumulate needs no cross-lane traffic.  (The tile was first
 // built on v_mfma_f32_32x32x2_f32 — same flops per cycle on paper; the 16x16 form measured
 // 7.5 % faster on the UCC-en launch in a same-box A/B: the chip holds a higher clock on it.)
-//   A (16 x 4): lane (i16 = l&15, kq = l>>4) <- LDS tile row 16b + i16   (staged once per block)
-//   B (4 x 16): lane (i16, kq)              <- streamed row 16b + i16    (HBM -> registers -> LDS -> registers)
+//   A (16 x 4): lane (i16 = l&15, kq = l>>4) <- streamed row 16b + i16    (HBM -> registers -> LDS -> registers)
+//   B (4 x 16): lane (i16, kq)              <- LDS tile (query) row 16b + i16   (staged once per block)
 // The streamed operand is fetched with fully coalesced 16-B/lane loads (8 rows x 128 B per wave
 // instruction, each byte read from HBM exactly once), parked in a wave-private, XOR-swizzled
 // 4-KiB LDS stage and read back as fragments; four 32-float chunks per wave (128 KiB per CU
 // with 8 waves) are always in flight in registers.  The k order inside a chunk is permuted
 // (lane group kq takes 16-B slots kq and 4 + kq); both operands use the same permutation,
-// which a dot product cannot see.  The finished 32x32 tile is turned through the wave's LDS
-// stage and stored as whole 128-byte rows of the score matrix S[query][row].  Top-k is a
+// which a dot product cannot see.  The finished 32x32 tile leaves as 16-byte stores
+// S[query][4 consecutive rows] straight from the accumulators (epilogue).  Top-k is a
 // second, slab-parallel pass over S (+8 % traffic at d = 768: 128 B written and read per
 // 3072-B row per 32 queries).
 #include "common.hpp"
@@ -81,11 +81,14 @@ __device__ __forceinline__ int stage_off(int row, int slot) { return row * 128 +
 #endif
 // 8 k-steps x 4 accumulator blocks = 32 MFMAs of 32 cycles per chunk; an accumulator is touched
 // every fourth instruction, well past the 40-cycle dependent latency.
+// A operand = streamed chunk rows, B operand = queries: a 16x16 result block then has the QUERY on the lane and four
+// consecutive chunk rows in the lane's registers (acc[bi][bj][r] = <row 16 bj + 4 kq + r, query 16 bi + i16>), so
+// S[query][row .. row+3] is one 16-byte store (see the epilogue).
 #define AMDR_MFMA_KSTEP(FX, FQ, U, COMP)                                                          \
-  AMDR_MFMA_STEP(FQ[0][U].COMP, FX[0][U].COMP, 0, 0)                                              \
-  AMDR_MFMA_STEP(FQ[0][U].COMP, FX[1][U].COMP, 0, 1)                                              \
-  AMDR_MFMA_STEP(FQ[1][U].COMP, FX[0][U].COMP, 1, 0)                                              \
-  AMDR_MFMA_STEP(FQ[1][U].COMP, FX[1][U].COMP, 1, 1)
+  AMDR_MFMA_STEP(FX[0][U].COMP, FQ[0][U].COMP, 0, 0)                                              \
+  AMDR_MFMA_STEP(FX[1][U].COMP, FQ[0][U].COMP, 0, 1)                                              \
+  AMDR_MFMA_STEP(FX[0][U].COMP, FQ[1][U].COMP, 1, 0)                                              \
+  AMDR_MFMA_STEP(FX[1][U].COMP, FQ[1][U].COMP, 1, 1)
 #define AMDR_MFMA_CHUNK(FX, FQ)                                                                   \
   AMDR_MFMA_KSTEP(FX, FQ, 0, x) AMDR_MFMA_KSTEP(FX, FQ, 0, y) AMDR_MFMA_KSTEP(FX, FQ, 0, z)       \
   AMDR_MFMA_KSTEP(FX, FQ, 0, w) AMDR_MFMA_KSTEP(FX, FQ, 1, x) AMDR_MFMA_KSTEP(FX, FQ, 1, y)       \
@@ -117,7 +120,6 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
   const v4f* qsv = reinterpret_cast<const v4f*>(smem);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned char* stage = smem + (size_t)d * 128 + (size_t)wave * kStageBufs * kStageBytes;
-  const int i = lane & 31, h = lane >> 5;  // store roles (epilogue)
   const int i16 = lane & 15, kq = lane >> 4;  // MFMA fragment roles
   // Lane-dependent parts of the fragment addresses, computed once: every other term is a
   // compile-time constant of the unrolled chunk loop and folds into the ds_read offset field.
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
     }
     wave_lds_fence();
     AMDR_READ_FRAGS(stage, 0, FX[0], FQ[0])
-    f32x4 acc[2][2];  // acc[bi][bj][r] = C[LDS-tile row 16 bi + 4 kq + r][streamed row 16 bj + i16]
+    f32x4 acc[2][2];  // acc[bi][bj][r] = <streamed row 16 bj + 4 kq + r, query (LDS-tile row) 16 bi + i16>
 #pragma unroll
     for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
@@ -244,27 +246,29 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
       AMDR_INTERLEAVE()
       wave_lds_fence();
     }
-    // The 32x32 tile goes through the wave's LDS stage (T[ti][tj] at ti*32 + (tj ^ ti): conflict-
-    // free to read along either index) so that S[query][chunk row] is written as whole 128-byte
-    // rows, two per instruction, in both orientations.  ti = row of the LDS tile, tj = streamed row.
-    float* tf = reinterpret_cast<float*>(stage);
+    // Epilogue: four 16-byte stores per lane, S[query 16 bi + i16][rows 16 bj + 4 kq .. + 3] — a store instruction
+    // covers 64 contiguous bytes of each of 16 query rows.  (Round 1 had the operands the other way round — query
+    // on the registers — and turned the 32x32 tile through the wave's LDS stage to store whole 128-byte rows:
+    // 16 ds_write + 16 ds_read + 16 four-byte stores per tile; with the matrix pipe taken out that kernel ran no
+    // faster on the 10 M-row scan, i.e. the non-MFMA stream bound it, and 8 / 16 / 32 queries per scan cost
+    // 4.9 / 5.4 / 5.8 ms.  With these stores: 4.9 / 5.1 / 5.8-5.9 ms, the UCC-en launch of this kernel 351 -> 344 us.
+    // Timing-only builds on the 10 M-row, 32-query scan: without the score stores 5.80 -> 5.10 ms (1.28 GB of writes
+    // = 4 % of the bytes cost 12 % of the time: they interleave with the read stream at the HBM), non-temporal
+    // stores 6.01 -> 6.10 ms.)  Rows past n inside the last 32-row tile repeat row n - 1 and land in the
+    // padding of S (ldS is a multiple of 32); slab boundaries are multiples of 32 rows.
 #pragma unroll
-    for (int bi = 0; bi < 2; ++bi)
+    for (int bi = 0; bi < 2; ++bi) {
+      const int q = q0 + 16 * bi + i16;
+      if (q < nq) {
+        float* srow = S + (size_t)q * ldS + r0 + 4 * kq;
+#if defined(AMDR_ABLATE) && AMDR_ABLATE == 3  // timing-only build: no score stores
+        if (acc[bi][0][0] == 12345.f) srow[0] = acc[bi][1][1];
+#else
 #pragma unroll
-      for (int bj = 0; bj < 2; ++bj)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int ti = 16 * bi + 4 * kq + r, tj = 16 * bj + i16;
-          tf[ti * 32 + (tj ^ ti)] = acc[bi][bj][r];
-        }
-    wave_lds_fence();
-#pragma unroll
-    for (int p = 0; p < 16; ++p) {  // LDS tile = queries q0 + ti, streamed = chunk rows r0 + tj
-      const int ti = 2 * p + h, tj = i;
-      const float v = tf[ti * 32 + (tj ^ ti)];
-      if (q0 + ti < nq && r0 + tj < row_hi) S[(size_t)(q0 + ti) * ldS + r0 + tj] = v;
+        for (int bj = 0; bj < 2; ++bj) *reinterpret_cast<f32x4*>(srow + 16 * bj) = acc[bi][bj];
+#endif
+      }
     }
-    wave_lds_fence();  // the next tile's first chunk is staged over T
   }
 }
 
