@@ -518,7 +518,9 @@ def _hbm_scan_one(torch, _native, device, X, Q, n, d, B, steps, warmup, k):
     maxerr = float(np.max(np.abs(gs - es)))
     kernel = plan.split(" ")[0].split("<")[0]
     batched = kernel != "dense_scan_topk_kernel"  # scores S[B, n] are written once and read once
-    bytes_per_launch = float(n) * d * 4 + B * d * 4 + (float(n) * B * 4 if batched else B * k * 8)
+    two_level = "two-level" in plan  # the scan keeps one maximum per 32-row tile and query, not every score
+    bytes_per_launch = float(n) * d * 4 + B * d * 4 + ((float(n) / 32 * B * 4 if two_level else float(n) * B * 4)
+                                                       if batched else B * k * 8)
     per_launch_ms = scan_ms / max(launches, 1)
     achieved = bytes_per_launch / (per_launch_ms * 1e-3) / 1e9
     out = {"workload": f"synthetic {n}x{d} fp32 rows in HBM, {B} queries/scan, top-{k}", "kernel": kernel, "plan": plan,

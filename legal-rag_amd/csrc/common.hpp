@@ -82,8 +82,13 @@ struct DenseMfmaPlan {
 };
 bool dense_mfma_supported(int d);
 void dense_mfma_plan(long n, int d, int nq, int k, DenseMfmaPlan* p);
+// mode 0: every row's score; 1: per-tile maxima; 2: re-scoring of the tiles in tile_list (dense_mfma.hip)
 int dense_mfma_launch_scores(const DenseMfmaPlan& p, const float* X, long n, int d, const float* Q, int nq, float* S,
-                             hipStream_t st);
+                             hipStream_t st, int mode = 0, const int* tile_list = nullptr,
+                             const int* tile_count = nullptr, long n_real = 0);
+// two-level top-k helpers: sorted unique list of the candidate tiles; column -> row id of the final hits
+int dense_tiles_unique_launch(const int64_t* tile_ids, int n_in, int* list, int* count, hipStream_t st);
+int dense_tiles_remap_launch(int64_t* ids, int total, const int* list, hipStream_t st);
 int dense_mfma_launch_topk(const DenseMfmaPlan& p, const float* S, long n, int nq, int k, void* part,
                            float* fin_scores, int64_t* fin_ids, hipStream_t st);
 

@@ -306,7 +306,7 @@ struct amdr_dense {
   // synchronised before the mutex is released).  A service thread in amdr_dense_search can
   // therefore never scribble over the score matrix of a search_batch still in flight on another
   // stream.  "_device" calls on ONE handle from SEVERAL streams remain the caller's to order.
-  DevBuf part[2], smat[2], qbuf, sbuf, ibuf;
+  DevBuf part[2], smat[2], aux[2], qbuf, sbuf, ibuf;  // aux: candidate tiles of the two-level top-k
   // optional HIP-event ring bracketing the scan kernel alone (bench.py roofline)
   std::vector<hipEvent_t> prof_ev;
   int prof_used = 0;
@@ -447,8 +447,117 @@ int run_search_batched(amdr_dense* h, int ws, const float* Q_dev, int nq, int k,
   return AMDR_OK;
 }
 
+// Two-level top-k for batches on a matrix far larger than the caches (the 10 M-row scans): the score matrix of the
+// plain two-pass form is 4 B x queries per row — 1.28 GB per 32 queries on 10 M rows, written and read back once, and
+// its stores interleave with the read stream at the HBM (timing-only build without them: 5.80 -> 5.10 ms).  Here:
+//   1. the tile kernel keeps, per 32-row tile and query, only the MAXIMUM  (n/32 x queries floats: 40 MB);
+//   2. top-k of each query's tile maxima -> k candidate tiles; their union, sorted, without duplicates;
+//   3. the tile kernel re-scores the candidate tiles (same loads, same MFMA k order: the same bits as a full pass);
+//   4. top-k of the re-scored columns, columns -> row ids.
+// Exact: at most k - 1 tiles hold a score above a query's k-th best s_k, so the k-th largest tile maximum T <= s_k
+// and every tile that holds one of the top k has a maximum >= T; among tiles AT T the lower tile ids are kept, which
+// is where the lower row ids of equal scores live.  k <= 32, queries x k <= 1 024 per pass.
+bool two_level_applies(const amdr_dense* h, int nq, int k) {
+  const char* e = getenv("AMDR_DENSE_TWO_LEVEL");
+  if (e && e[0] == '0') return false;
+  if (!(nq >= kBatchedMin && h->n > 0 && dense_mfma_supported(h->d))) return false;
+  if (k > 32) return false;
+  const long tiles = ((long)h->n + 31) / 32;
+  if (e && e[0] == '1') return tiles >= 2L * k;  // pinned on (tests): any matrix with enough tiles
+  if (dense_panel_supported((long)h->n, h->d, batched_chunk(h, nq))) return false;  // >= 96 queries: the panel kernel
+  return dense_stream_nontemporal((long)h->n, h->d) && tiles >= 64L * k;
+}
+int two_level_chunk(int nq, int k) {
+  int c = (1024 / k) / 32 * 32;
+  if (c < 32) c = 32;
+  if (c > 96) c = 96;
+  return nq < c ? nq : c;
+}
+struct TwoLevelPlan {
+  DenseMfmaPlan scan, tk1, pass2;  // full scan (mode 1), top-k over the tile maxima, candidate re-scoring + its top-k
+  long tiles, cand_rows;
+  size_t m_bytes, s2_bytes, aux_bytes, part_bytes;
+};
+void two_level_plan(const amdr_dense* h, int m, int k, TwoLevelPlan* t) {
+  t->tiles = ((long)h->n + 31) / 32;
+  dense_mfma_plan((long)h->n, h->d, m, k, &t->scan);
+  dense_mfma_plan(t->tiles, h->d, m, k, &t->tk1);  // only its top-k half is used: columns = tiles
+  t->cand_rows = (long)m * k * 32;
+  dense_mfma_plan(t->cand_rows, h->d, m, k, &t->pass2);
+  t->m_bytes = ((size_t)m * t->tk1.ld * sizeof(float) + 255) / 256 * 256;
+  t->s2_bytes = (size_t)m * t->pass2.ld * sizeof(float);
+  t->aux_bytes = (size_t)m * k * (sizeof(int64_t) + sizeof(float)) + (size_t)(m * k + 64) * sizeof(int) + 256;
+  t->part_bytes = t->tk1.part_bytes > t->pass2.part_bytes ? t->tk1.part_bytes : t->pass2.part_bytes;
+}
+int two_level_ensure(amdr_dense* h, int ws, int nq, int k) {
+  TwoLevelPlan t;
+  two_level_plan(h, two_level_chunk(nq, k), k, &t);
+  int rc = h->smat[ws].ensure(t.m_bytes + t.s2_bytes);
+  if (!rc) rc = h->part[ws].ensure(t.part_bytes);
+  if (!rc) rc = h->aux[ws].ensure(t.aux_bytes);
+  return rc;
+}
+
+// one top-k pass over a [m][ld] score matrix with `cols` valid columns (slab lists + merge, or direct)
+int topk_pass(const DenseMfmaPlan& p, const float* S, long cols, int m, int k, DevBuf& partb, float* out_scores,
+              int64_t* out_ids, hipStream_t st) {
+  const bool direct = p.slabs == 1;
+  int rc = dense_mfma_launch_topk(p, S, cols, m, k, partb.p, direct ? out_scores : nullptr, direct ? out_ids : nullptr, st);
+  if (rc) return rc;
+  if (!direct) {
+    size_t lds = (size_t)kWaves * p.cap * sizeof(C32) + kWaves * sizeof(int);
+    hipLaunchKernelGGL(dense_merge_kernel, dim3(m), dim3(256), lds, st, partb.as<C32>(), p.slabs, m, k, p.cap, out_scores,
+                       (long long*)out_ids);
+    AMDR_HIP(hipGetLastError());
+  }
+  return AMDR_OK;
+}
+
+int run_search_two_level(amdr_dense* h, int ws, const float* Q_dev, int nq, int k, float* scores_dev, int64_t* ids_dev,
+                         hipStream_t st) {
+  int rc = two_level_ensure(h, ws, nq, k);
+  if (rc) return rc;
+  const int chunk = two_level_chunk(nq, k);
+  for (int q0 = 0; q0 < nq; q0 += chunk) {
+    const int m = nq - q0 < chunk ? nq - q0 : chunk;
+    TwoLevelPlan t;
+    two_level_plan(h, m, k, &t);
+    float* M = h->smat[ws].as<float>();
+    float* S2 = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(h->smat[ws].p) + t.m_bytes);
+    unsigned char* aux = reinterpret_cast<unsigned char*>(h->aux[ws].p);
+    int64_t* tile_ids = reinterpret_cast<int64_t*>(aux);
+    float* tile_max = reinterpret_cast<float*>(aux + (size_t)m * k * sizeof(int64_t));
+    int* list = reinterpret_cast<int*>(aux + (size_t)m * k * (sizeof(int64_t) + sizeof(float)));
+    int* count = list + (size_t)m * k;
+    const float* Qc = Q_dev + (size_t)q0 * h->d;
+    // 1. tile maxima (the scan: this is the launch the profiling events bracket)
+    DenseMfmaPlan scan = t.scan;
+    scan.ld = t.tk1.ld;
+    const bool prof = h->prof_on && (size_t)(h->prof_used + 2) <= h->prof_ev.size();
+    if (prof) AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
+    if ((rc = dense_mfma_launch_scores(scan, h->X, (long)h->n, h->d, Qc, m, M, st, 1))) return rc;
+    if (prof) {
+      AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
+      h->prof_used += 2;
+    }
+    // 2. k candidate tiles per query, their sorted union
+    if ((rc = topk_pass(t.tk1, M, t.tiles, m, k, h->part[ws], tile_max, tile_ids, st))) return rc;
+    if ((rc = dense_tiles_unique_launch(tile_ids, m * k, list, count, st))) return rc;
+    // 3. exact scores of the candidate tiles' rows
+    if ((rc = dense_mfma_launch_scores(t.pass2, h->X, t.cand_rows, h->d, Qc, m, S2, st, 2, list, count, (long)h->n)))
+      return rc;
+    // 4. top-k of the candidates, columns -> row ids
+    if ((rc = topk_pass(t.pass2, S2, t.cand_rows, m, k, h->part[ws], scores_dev + (size_t)q0 * k, ids_dev + (size_t)q0 * k,
+                        st)))
+      return rc;
+    if ((rc = dense_tiles_remap_launch(ids_dev + (size_t)q0 * k, m * k, list, st))) return rc;
+  }
+  return AMDR_OK;
+}
+
 int run_search(amdr_dense* h, int ws, const float* Q_dev, int nq, int k, float* scores_dev, int64_t* ids_dev,
                hipStream_t st) {
+  if (two_level_applies(h, nq, k)) return run_search_two_level(h, ws, Q_dev, nq, k, scores_dev, ids_dev, st);
   if (nq >= kBatchedMin && h->n > 0 && dense_mfma_supported(h->d))
     return run_search_batched(h, ws, Q_dev, nq, k, scores_dev, ids_dev, st);
   if (h->n > 0 && h->n <= kRowWavesMax) return run_search_batched(h, ws, Q_dev, nq, k, scores_dev, ids_dev, st, true);
@@ -591,7 +700,9 @@ int amdr_dense_reserve(amdr_dense_t* h, int32_t nq_max, int32_t k_max) {
   make_plan(h->n, h->d, nq_max, k_max, &p);
   int rc = h->part[0].ensure(p.part_bytes);
   if (rc) return rc;
-  if (nq_max >= kBatchedMin && h->n > 0 && dense_mfma_supported(h->d)) {
+  if (two_level_applies(h, nq_max, k_max)) {
+    if ((rc = two_level_ensure(h, 0, nq_max, k_max))) return rc;
+  } else if (nq_max >= kBatchedMin && h->n > 0 && dense_mfma_supported(h->d)) {
     DenseMfmaPlan mp;
     dense_mfma_plan((long)h->n, h->d, batched_chunk(h, nq_max), k_max, &mp);
     if ((rc = h->smat[0].ensure(mp.s_bytes))) return rc;
@@ -678,6 +789,16 @@ int amdr_dense_plan_info(const amdr_dense_t* h, int32_t nq, int32_t k, char* buf
     snprintf(buf, buf_len, "empty index");
     return AMDR_OK;
   }
+  if (two_level_applies(h, nq, k)) {
+    TwoLevelPlan t;
+    const int m = two_level_chunk(nq, k);
+    two_level_plan(h, m, k, &t);
+    snprintf(buf, buf_len,
+             "dense_mfma_scores_kernel tile-maxima grid=%dx%d queries_per_launch=%d two-level: top-%d of %ld tile maxima "
+             "+ re-scoring of <= %d candidate tiles + top-k",
+             t.scan.grid_x, t.scan.grid_y, m, k, t.tiles, m * k);
+    return AMDR_OK;
+  }
   const bool batched = nq >= kBatchedMin && dense_mfma_supported(h->d);
   if (batched || h->n <= kRowWavesMax) {
     const int m = batched_chunk(h, nq);
@@ -748,6 +869,7 @@ int amdr_dense_destroy(amdr_dense_t* h) {
   for (int w = 0; w < 2; ++w) {
     h->part[w].release();
     h->smat[w].release();
+    h->aux[w].release();
   }
   h->qbuf.release();
   h->sbuf.release();

@@ -112,7 +112,15 @@ template <int D8, int WAVES, bool NTL>  // NTL: non-temporal loads of the stream
 __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const float* __restrict__ X, long n,
                                                                  const float* __restrict__ Q, int nq,
                                                                  long rows_per_block, int gx, int gy, long ldS,
-                                                                 float* __restrict__ S /*[queries][ldS]*/) {
+                                                                 float* __restrict__ S /*[queries][ldS]*/, int mode,
+                                                                 const int* __restrict__ tile_list,
+                                                                 const int* __restrict__ tile_count, long n_real) {
+  // mode 0: S[query][row] for every row.
+  // mode 1: S[query][tile] = MAXIMUM of the query's scores over the 32-row tile (first pass of the two-level
+  //         top-k of a large scan: dense.hip run_search_two_level).
+  // mode 2: `n` counts VIRTUAL rows, 32 per entry of tile_list; virtual tile t reads chunk tile tile_list[t]
+  //         (t < *tile_count, else it is filled with -FLT_MAX) and writes S[query][32 t ..]: the exact re-scoring of
+  //         the candidate tiles — same loads, same MFMA k order, the same bits as mode 0.
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int d = D8 * 8;
   constexpr int NCH = d / kKC;  // chunks per row: 12 / 24 / 32 (always even: d % 64 == 0)
@@ -192,13 +200,32 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
   // loader role of this lane inside a 1-KiB piece: 8 rows x 8 slots
   const int lrow = lane >> 3, lslot = lane & 7;
 
+  const int n_list = (mode == 2) ? *tile_count : 0;
   for (long r0 = row_lo + (long)wave * 32; r0 < row_hi; r0 += (long)WAVES * 32) {
+    long src0 = r0, src_hi = row_hi;  // rows actually read
+    if (mode == 2) {
+      const int t = (int)(r0 >> 5);
+      if (t >= n_list) {  // beyond the candidate list: columns that can never win
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi) {
+          const int q = q0 + 16 * bi + i16;
+          if (q < nq) {
+            float* srow = S + (size_t)q * ldS + r0 + 4 * kq;
+#pragma unroll
+            for (int bj = 0; bj < 2; ++bj) *reinterpret_cast<f32x4*>(srow + 16 * bj) = f32x4{-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+          }
+        }
+        continue;
+      }
+      src0 = (long)tile_list[t] * 32;
+      src_hi = n_real;
+    }
     // global pointers of the 8 pieces (rows 4p + lrow), clamped at the slab end
     const float* gp[kPieces];
 #pragma unroll
     for (int p = 0; p < kPieces; ++p) {
-      long r = r0 + 8 * p + lrow;
-      if (r >= row_hi) r = row_hi - 1;
+      long r = src0 + 8 * p + lrow;
+      if (r >= src_hi) r = src_hi - 1;
       gp[p] = X + (size_t)r * d + lslot * 4;
     }
     // Software pipeline; every index below is a compile-time constant once the chunk loop is
@@ -256,6 +283,20 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
     // = 4 % of the bytes cost 12 % of the time: they interleave with the read stream at the HBM), non-temporal
     // stores 6.01 -> 6.10 ms.)  Rows past n inside the last 32-row tile repeat row n - 1 and land in the
     // padding of S (ldS is a multiple of 32); slab boundaries are multiples of 32 rows.
+    if (mode == 1) {
+      // tile maxima: 7 v_max per query block in the lane, two exchanges over the four kq groups (rows past the end
+      // of the matrix repeat its last row: no effect on a maximum)
+#pragma unroll
+      for (int bi = 0; bi < 2; ++bi) {
+        float m = fmaxf(fmaxf(fmaxf(acc[bi][0][0], acc[bi][0][1]), fmaxf(acc[bi][0][2], acc[bi][0][3])),
+                        fmaxf(fmaxf(acc[bi][1][0], acc[bi][1][1]), fmaxf(acc[bi][1][2], acc[bi][1][3])));
+        m = fmaxf(m, __uint_as_float(lane_xor<16>(__float_as_uint(m))));
+        m = fmaxf(m, __uint_as_float(lane_xor<32>(__float_as_uint(m))));
+        const int q = q0 + 16 * bi + i16;
+        if (kq == 0 && q < nq) S[(size_t)q * ldS + (r0 >> 5)] = m;
+      }
+      continue;
+    }
 #pragma unroll
     for (int bi = 0; bi < 2; ++bi) {
       const int q = q0 + 16 * bi + i16;
@@ -265,7 +306,15 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
         if (acc[bi][0][0] == 12345.f) srow[0] = acc[bi][1][1];
 #else
 #pragma unroll
-        for (int bj = 0; bj < 2; ++bj) *reinterpret_cast<f32x4*>(srow + 16 * bj) = acc[bi][bj];
+        for (int bj = 0; bj < 2; ++bj) {
+          f32x4 v = acc[bi][bj];
+          if (mode == 2) {  // rows past the end of the matrix inside the last tile are no candidates
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (src0 + 16 * bj + 4 * kq + r >= n_real) v[r] = -FLT_MAX;
+          }
+          *reinterpret_cast<f32x4*>(srow + 16 * bj) = v;
+        }
 #endif
       }
     }
@@ -438,6 +487,67 @@ __global__ __launch_bounds__(64) void scores_pair_topk_kernel(const float* __res
   }
 }
 
+// Two-level top-k of a large scan, step 2: the <= 1 024 candidate tile ids (k per query, -1 = none) -> ascending
+// list without duplicates + its length.  One wave; bitonic sort in LDS (descending on id + 1, so that "none" sorts
+// last), neighbour compare, one prefix sum.
+__global__ __launch_bounds__(64) void tiles_unique_kernel(const long long* __restrict__ tile_ids, int n_in, int cap,
+                                                          int* __restrict__ list, int* __restrict__ count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  C32* buf = reinterpret_cast<C32*>(smem);
+  const int lane = threadIdx.x;
+  for (int i = lane; i < cap; i += 64) {
+    const long long v = i < n_in ? tile_ids[i] : -1ll;
+    buf[i].c = v >= 0 ? (u64)(v + 1) : 0ull;
+  }
+  wave_bitonic_sort_desc(buf, cap, lane);
+  const int per = cap / 64;  // cap is a power of two >= 64
+  int mine = 0;
+  for (int j = 0; j < per; ++j) {
+    const int i = lane * per + j;
+    const u64 x = buf[i].c, prev = i ? buf[i - 1].c : ~0ull;
+    mine += (x != 0ull && x != prev) ? 1 : 0;
+  }
+  int incl = mine;
+#pragma unroll
+  for (int s2 = 1; s2 < 64; s2 <<= 1) {
+    const int o = __shfl_up(incl, s2);
+    incl += (lane >= s2) ? o : 0;
+  }
+  const int total = __builtin_amdgcn_readlane(incl, 63);
+  int pos = incl - mine;
+  for (int j = 0; j < per; ++j) {
+    const int i = lane * per + j;
+    const u64 x = buf[i].c, prev = i ? buf[i - 1].c : ~0ull;
+    if (x != 0ull && x != prev) list[total - 1 - pos++] = (int)(x - 1);  // descending order in, ascending out
+  }
+  if (lane == 0) *count = total;
+}
+
+// step 4: the final hits carry COLUMNS of the re-scored candidate matrix (32 per list entry); columns ascend with the
+// row ids (the list is ascending), so ties were already broken towards the lower id.
+__global__ __launch_bounds__(256) void tiles_remap_ids_kernel(long long* __restrict__ ids, int total,
+                                                              const int* __restrict__ list) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < total) {
+    const long long c = ids[i];
+    if (c >= 0) ids[i] = (long long)list[c >> 5] * 32 + (c & 31);
+  }
+}
+
+int dense_tiles_unique_launch(const int64_t* tile_ids, int n_in, int* list, int* count, hipStream_t st) {
+  int cap = 64;
+  while (cap < n_in) cap <<= 1;
+  hipLaunchKernelGGL(tiles_unique_kernel, dim3(1), dim3(64), (size_t)cap * sizeof(C32), st, (const long long*)tile_ids, n_in,
+                     cap, list, count);
+  AMDR_HIP(hipGetLastError());
+  return AMDR_OK;
+}
+int dense_tiles_remap_launch(int64_t* ids, int total, const int* list, hipStream_t st) {
+  hipLaunchKernelGGL(tiles_remap_ids_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, (long long*)ids, total, list);
+  AMDR_HIP(hipGetLastError());
+  return AMDR_OK;
+}
+
 bool dense_mfma_supported(int d) { return d >= 64 && d <= 1024 && d % 64 == 0; }
 
 // Plan shared by reserve and launch.
@@ -499,7 +609,7 @@ void dense_mfma_plan(long n, int d, int nq, int k, DenseMfmaPlan* p) {
 
 template <int D8, int WAVES, bool NTL>
 static int launch_scores(const DenseMfmaPlan& p, const float* X, long n, const float* Q, int nq, float* S,
-                         hipStream_t st) {
+                         hipStream_t st, int mode, const int* tile_list, const int* tile_count, long n_real) {
   // 128-160 KiB of dynamic LDS needs the opt-in.  The attribute belongs to the (function, device)
   // pair, the C ABI takes a device ordinal, and setting it is cheap: set on every launch for the
   // current device rather than remembering "done" per process.
@@ -507,19 +617,20 @@ static int launch_scores(const DenseMfmaPlan& p, const float* X, long n, const f
                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                D8 * 8 * 32 * (int)sizeof(float) + WAVES * kStageBufs * kStageBytes));
   hipLaunchKernelGGL((dense_mfma_scores_kernel<D8, WAVES, NTL>), dim3(p.grid_x * p.grid_y), dim3(WAVES * 64),
-                     p.lds_scores, st, X, n, Q, nq, p.rows_per_block, p.grid_x, p.grid_y, p.ld, S);
+                     p.lds_scores, st, X, n, Q, nq, p.rows_per_block, p.grid_x, p.grid_y, p.ld, S, mode, tile_list, tile_count,
+                     n_real);
   return AMDR_OK;
 }
 
 int dense_mfma_launch_scores(const DenseMfmaPlan& p, const float* X, long n, int d, const float* Q, int nq, float* S,
-                             hipStream_t st) {
+                             hipStream_t st, int mode, const int* tile_list, const int* tile_count, long n_real) {
   int rc = AMDR_OK;
-  const bool nt = dense_stream_nontemporal(n, d);
+  const bool nt = dense_stream_nontemporal(mode == 2 ? n_real : n, d) && mode != 2;  // candidate tiles are re-read: cacheable
   switch (d) {
 #define AMDR_CASE(D)                                                          \
   case D:                                                                     \
-    rc = nt ? launch_scores<D / 8, scores_waves(D), true>(p, X, n, Q, nq, S, st)   \
-            : launch_scores<D / 8, scores_waves(D), false>(p, X, n, Q, nq, S, st); \
+    rc = nt ? launch_scores<D / 8, scores_waves(D), true>(p, X, n, Q, nq, S, st, mode, tile_list, tile_count, n_real)   \
+            : launch_scores<D / 8, scores_waves(D), false>(p, X, n, Q, nq, S, st, mode, tile_list, tile_count, n_real); \
     break;
     AMDR_CASE(64) AMDR_CASE(128) AMDR_CASE(192) AMDR_CASE(256) AMDR_CASE(320) AMDR_CASE(384)
     AMDR_CASE(448) AMDR_CASE(512) AMDR_CASE(576) AMDR_CASE(640) AMDR_CASE(704) AMDR_CASE(768)

@@ -167,6 +167,40 @@ def test_dense_panel_agrees_bitwise_with_tiles(nat, monkeypatch):
     assert np.array_equal(out["0"][0], out["1"][0])
 
 
+def test_dense_two_level_topk_equals_full_score_matrix(nat, monkeypatch):
+    """Large-scan form (dense.hip run_search_two_level): per-tile maxima -> candidate tiles -> exact re-scoring -> top-k.
+    AMDR_DENSE_TWO_LEVEL=1 pins it on small matrices, =0 pins the full score matrix; both must return the same ids
+    and the same score bits — ragged last tile, 5..95 queries, k = 1..32, and a matrix made of repeated rows (exact
+    ties across tiles: lower id first) — and the oracle's answer."""
+    rng = np.random.default_rng(91)
+    cases = [(5000, 128, 32, 10), (4999, 768, 5, 1), (3333, 256, 95, 10), (2100, 64, 40, 32), (70000, 64, 33, 7)]
+    for n, d, nq, k in cases:
+        X, Q = unit_rows(rng, n, d), unit_rows(rng, nq, d)
+        out = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("AMDR_DENSE_TWO_LEVEL", flag)
+            idx = nat.DenseIndex(X)
+            out[flag] = idx.search(Q, k)
+            idx.close()
+        assert np.array_equal(out["1"][1], out["0"][1]), (n, d, nq, k)
+        assert np.array_equal(out["1"][0], out["0"][0]), (n, d, nq, k)
+    monkeypatch.setenv("AMDR_DENSE_TWO_LEVEL", "1")
+    check_dense(nat, unit_rows(rng, 4097, 192), unit_rows(rng, 17, 192), 10)
+    base = unit_rows(rng, 700, 128)
+    X = np.concatenate([base] * 5, axis=0)  # every row five times, 700 apart: ties in different tiles
+    Q = unit_rows(rng, 12, 128)
+    idx = nat.DenseIndex(X)
+    s, i = idx.search(Q, 10)
+    idx.close()
+    ref = (base.astype(np.float64) @ Q.astype(np.float64).T).T
+    for b in range(12):
+        top = np.argsort(-ref[b], kind="stable")[:2]
+        assert i[b, :5].tolist() == [int(top[0]) + 700 * j for j in range(5)]
+        assert i[b, 5:10].tolist() == [int(top[1]) + 700 * j for j in range(5)]
+        assert len(set(s[b, :5].tolist())) == 1 and len(set(s[b, 5:].tolist())) == 1
+
+
+
 def test_dense_golden_fixture(nat):
     """Seeded fixture of SURVEY.md §8c(3): X[4096,768], Q[16,768], rng(0)."""
     g = np.load(str(__import__("conftest").GOLDEN / "dense_flatip_golden.npz"))
