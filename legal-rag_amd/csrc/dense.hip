@@ -456,19 +456,19 @@ int run_search_batched(amdr_dense* h, int ws, const float* Q_dev, int nq, int k,
 //   4. top-k of the re-scored columns, columns -> row ids.
 // Exact: at most k - 1 tiles hold a score above a query's k-th best s_k, so the k-th largest tile maximum T <= s_k
 // and every tile that holds one of the top k has a maximum >= T; among tiles AT T the lower tile ids are kept, which
-// is where the lower row ids of equal scores live.  k <= 32, queries x k <= 1 024 per pass.
+// is where the lower row ids of equal scores live.  queries x k <= 8 192 candidate tiles per pass.
 bool two_level_applies(const amdr_dense* h, int nq, int k) {
   const char* e = getenv("AMDR_DENSE_TWO_LEVEL");
   if (e && e[0] == '0') return false;
   if (!(nq >= kBatchedMin && h->n > 0 && dense_mfma_supported(h->d))) return false;
-  if (k > 32) return false;
   const long tiles = ((long)h->n + 31) / 32;
   if (e && e[0] == '1') return tiles >= 2L * k;  // pinned on (tests): any matrix with enough tiles
   if (dense_panel_supported((long)h->n, h->d, batched_chunk(h, nq))) return false;  // >= 96 queries: the panel kernel
   return dense_stream_nontemporal((long)h->n, h->d) && tiles >= 64L * k;
 }
+constexpr int kTwoLevelTilesMax = 8192;  // candidate tiles per pass (queries x k): one wave sorts them in 64 KiB of LDS
 int two_level_chunk(int nq, int k) {
-  int c = (1024 / k) / 32 * 32;
+  int c = (kTwoLevelTilesMax / k) / 32 * 32;  // >= 32 for every k <= AMDR_MAX_K = 256
   if (c < 32) c = 32;
   if (c > 96) c = 96;
   return nq < c ? nq : c;

@@ -487,7 +487,7 @@ __global__ __launch_bounds__(64) void scores_pair_topk_kernel(const float* __res
   }
 }
 
-// Two-level top-k of a large scan, step 2: the <= 1 024 candidate tile ids (k per query, -1 = none) -> ascending
+// Two-level top-k of a large scan, step 2: the <= 8 192 candidate tile ids (k per query, -1 = none) -> ascending
 // list without duplicates + its length.  One wave; bitonic sort in LDS (descending on id + 1, so that "none" sorts
 // last), neighbour compare, one prefix sum.
 __global__ __launch_bounds__(64) void tiles_unique_kernel(const long long* __restrict__ tile_ids, int n_in, int cap,

@@ -170,10 +170,11 @@ def test_dense_panel_agrees_bitwise_with_tiles(nat, monkeypatch):
 def test_dense_two_level_topk_equals_full_score_matrix(nat, monkeypatch):
     """Large-scan form (dense.hip run_search_two_level): per-tile maxima -> candidate tiles -> exact re-scoring -> top-k.
     AMDR_DENSE_TWO_LEVEL=1 pins it on small matrices, =0 pins the full score matrix; both must return the same ids
-    and the same score bits — ragged last tile, 5..95 queries, k = 1..32, and a matrix made of repeated rows (exact
+    and the same score bits — ragged last tile, 5..95 queries, k = 1..256, and a matrix made of repeated rows (exact
     ties across tiles: lower id first) — and the oracle's answer."""
     rng = np.random.default_rng(91)
-    cases = [(5000, 128, 32, 10), (4999, 768, 5, 1), (3333, 256, 95, 10), (2100, 64, 40, 32), (70000, 64, 33, 7)]
+    cases = [(5000, 128, 32, 10), (4999, 768, 5, 1), (3333, 256, 95, 10), (2100, 64, 40, 32), (70000, 64, 33, 7),
+             (20000, 64, 40, 80), (40000, 64, 33, 256)]
     for n, d, nq, k in cases:
         X, Q = unit_rows(rng, n, d), unit_rows(rng, nq, d)
         out = {}
