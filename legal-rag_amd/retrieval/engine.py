@@ -32,6 +32,20 @@ class BatchResult:
     colbert_ids: Optional[torch.Tensor] = None
     colbert_scores: Optional[torch.Tensor] = None
     rerank: Optional[torch.Tensor] = None  # f64 [nq, max_out, 2] (raw, norm) after rerank_blend
+    packed: Optional[torch.Tensor] = None  # u8: ids | vals | mask | count in ONE allocation (one D2H for the host API)
+
+    def to_host(self):
+        """(ids, vals, mask, count) as numpy arrays through ONE device-to-host copy (the first `.cpu()` of a result
+        waits for the kernels; three more copies of a single query's few hundred bytes cost ~10 us each)."""
+        if self.packed is None:
+            return (self.ids.cpu().numpy(), self.vals.cpu().numpy(), self.mask.cpu().numpy(), self.count.cpu().numpy())
+        nq, mo = self.ids.shape
+        h = self.packed.cpu().numpy()
+        o1 = nq * mo * 8
+        o2 = o1 + nq * mo * _native.FUSE_NVALS * 8
+        o3 = o2 + nq * mo * 4
+        return (h[:o1].view("int64").reshape(nq, mo), h[o1:o2].view("float64").reshape(nq, mo, _native.FUSE_NVALS),
+                h[o2:o3].view("int32").reshape(nq, mo), h[o3:o3 + nq * 4].view("int32"))
 
 
 def _stream() -> int:
@@ -103,13 +117,17 @@ class HybridEngine:
         b, kb = chan(bm25, self.maps[1])
         c, kc = chan(colbert, self.maps[2])
         mo = kd + kb + kc
-        ids = self._buf("fi", (nq, mo), torch.int64)
-        vals = self._buf("fv", (nq, mo, _native.FUSE_NVALS), torch.float64)
-        mask = self._buf("fm", (nq, mo), torch.int32)
-        count = self._buf("fc", (nq,), torch.int32)
+        o1 = nq * mo * 8
+        o2 = o1 + nq * mo * _native.FUSE_NVALS * 8
+        o3 = o2 + nq * mo * 4
+        pk = self._buf("fpk", (o3 + nq * 4,), torch.uint8)  # the four outputs side by side: one D2H serves the host API
+        ids = pk[:o1].view(torch.int64).view(nq, mo)
+        vals = pk[o1:o2].view(torch.float64).view(nq, mo, _native.FUSE_NVALS)
+        mask = pk[o2:o3].view(torch.int32).view(nq, mo)
+        count = pk[o3:].view(torch.int32)
         _native.fuse_device(params, nq, d, b, c, ids.data_ptr(), vals.data_ptr(), mask.data_ptr(), count.data_ptr(),
                             device=self.device, stream=_stream())
-        return BatchResult(ids=ids, vals=vals, mask=mask, count=count)
+        return BatchResult(ids=ids, vals=vals, mask=mask, count=count, packed=pk)
 
     def rerank_blend(self, res: BatchResult, ce_raw: torch.Tensor, beta: float) -> BatchResult:
         nq, mo = res.ids.shape

@@ -486,14 +486,16 @@ class HybridRetriever:
                                    device=dev)
                 engines[col is not None] = eng
                 self.__dict__["_native_engine"] = engines
+            # BM25 query CSR in ONE host-to-device copy: q_ptr (i64) then q_terms (i32) in one byte buffer
+            qp8, qt8 = qp.view(np.uint8), qt.view(np.uint8)
+            qbuf = torch.from_numpy(np.concatenate([qp8, qt8])).to(tdev, non_blocking=True)
+            q_ptr_d = qbuf[: qp8.size].view(torch.int64)
+            q_terms_d = qbuf[qp8.size:].view(torch.int32) if qt8.size else torch.zeros(1, dtype=torch.int32, device=tdev)
             res = eng.search_batch(self._params(kn, min_final), eff,
-                                   q_emb=q_emb,
-                                   q_terms=torch.from_numpy(qt).to(tdev, non_blocking=True),
-                                   q_ptr=torch.from_numpy(qp).to(tdev, non_blocking=True),
+                                   q_emb=q_emb, q_terms=q_terms_d, q_ptr=q_ptr_d,
                                    q_tok=torch.from_numpy(q_tok_h).to(tdev, non_blocking=True) if q_tok_h is not None else None)
-            # ONE synchronise: the D2H copies below run on the same stream and block until the data is there
-            ids, vals, mask, cnt = (res.ids.cpu().numpy(), res.vals.cpu().numpy(), res.mask.cpu().numpy(),
-                                    res.count.cpu().numpy())
+            # ONE synchronise and ONE device-to-host copy (the four outputs share an allocation)
+            ids, vals, mask, cnt = res.to_host()
         if arrays:
             return (ids, vals, mask, cnt, np.asarray(exact, dtype=bool)), (t1, t2, t3)
         chunks = store.chunks

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""cProfile of HybridRetriever.search (one query per call, dense + BM25) on the UCC-en fixture (GPU box)."""
+import cProfile
+import pstats
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+from legal_rag_amd.config import AppConfig  # noqa: E402
+from legal_rag_amd.evaluation import synthetic_queries  # noqa: E402
+from legal_rag_amd.retrieval.builders.bm25_builder import build_bm25_index  # noqa: E402
+from legal_rag_amd.retrieval.builders.faiss_builder import build_faiss_index  # noqa: E402
+from legal_rag_amd.retrieval.corpus_loader import load_chunks_from_dir  # noqa: E402
+from legal_rag_amd.retrieval.hybrid_retriever import HybridRetriever  # noqa: E402
+
+with tempfile.TemporaryDirectory(prefix="amdr_prof_") as tmp:
+    cfg = AppConfig.for_data_dir(tmp, "en")
+    cfg.retrieval.encoder_backend = "hashing"
+    cfg.retrieval.device = 0
+    cfg.retrieval.enable_graph = False
+    cfg.retrieval.enable_colbert = cfg.retrieval.enable_rerank = False
+    chunks = load_chunks_from_dir(str(ROOT / "tests" / "golden" / "corpus"), "law_en.jsonl")
+    build_faiss_index(cfg, chunks)
+    build_bm25_index(cfg, chunks)
+    qs = [q for q, _, _ in synthetic_queries(chunks, seed=0)]
+    r = HybridRetriever(cfg)
+    for q in qs[:30]:
+        r.search(q, top_k=10)
+    t = time.perf_counter()
+    for q in qs[30:330]:
+        r.search(q, top_k=10)
+    print("mean ms per search():", (time.perf_counter() - t) / 300 * 1e3)
+    pr = cProfile.Profile()
+    pr.enable()
+    for q in qs[30:330]:
+        r.search(q, top_k=10)
+    pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(22)
