@@ -489,12 +489,20 @@ void two_level_plan(const amdr_dense* h, int m, int k, TwoLevelPlan* t) {
   t->aux_bytes = (size_t)m * k * (sizeof(int64_t) + sizeof(float)) + (size_t)(m * k + 64) * sizeof(int) + 256;
   t->part_bytes = t->tk1.part_bytes > t->pass2.part_bytes ? t->tk1.part_bytes : t->pass2.part_bytes;
 }
-int two_level_ensure(amdr_dense* h, int ws, int nq, int k) {
-  TwoLevelPlan t;
-  two_level_plan(h, two_level_chunk(nq, k), k, &t);
-  int rc = h->smat[ws].ensure(t.m_bytes + t.s2_bytes);
-  if (!rc) rc = h->part[ws].ensure(t.part_bytes);
-  if (!rc) rc = h->aux[ws].ensure(t.aux_bytes);
+// Workspace for (nq, k); with all_k for every k' <= k as well — a smaller k takes MORE queries per pass, i.e. a larger
+// matrix of tile maxima, and amdr_dense_reserve promises that calls within (nq_max, k_max) allocate nothing.
+int two_level_ensure(amdr_dense* h, int ws, int nq, int k, bool all_k = false) {
+  size_t smat = 0, part = 0, aux = 0;
+  for (int kk = all_k ? 1 : k; kk <= k; ++kk) {
+    TwoLevelPlan t;
+    two_level_plan(h, two_level_chunk(nq, kk), kk, &t);
+    smat = t.m_bytes + t.s2_bytes > smat ? t.m_bytes + t.s2_bytes : smat;
+    part = t.part_bytes > part ? t.part_bytes : part;
+    aux = t.aux_bytes > aux ? t.aux_bytes : aux;
+  }
+  int rc = h->smat[ws].ensure(smat);
+  if (!rc) rc = h->part[ws].ensure(part);
+  if (!rc) rc = h->aux[ws].ensure(aux);
   return rc;
 }
 
@@ -700,8 +708,12 @@ int amdr_dense_reserve(amdr_dense_t* h, int32_t nq_max, int32_t k_max) {
   make_plan(h->n, h->d, nq_max, k_max, &p);
   int rc = h->part[0].ensure(p.part_bytes);
   if (rc) return rc;
+  // batches of 5-95 queries on a large matrix take the two-level form, longer ones the panel kernel + score matrix
+  const int nq_two = nq_max < 95 ? nq_max : 95;
+  if (two_level_applies(h, nq_two, k_max)) {
+    if ((rc = two_level_ensure(h, 0, nq_two, k_max, true))) return rc;
+  }
   if (two_level_applies(h, nq_max, k_max)) {
-    if ((rc = two_level_ensure(h, 0, nq_max, k_max))) return rc;
   } else if (nq_max >= kBatchedMin && h->n > 0 && dense_mfma_supported(h->d)) {
     DenseMfmaPlan mp;
     dense_mfma_plan((long)h->n, h->d, batched_chunk(h, nq_max), k_max, &mp);

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""cProfile of HybridRetriever.search (one query per call, dense + BM25) on the UCC-en fixture (GPU box)."""
+"""cProfile of HybridRetriever.search (one query per call) on the UCC-en fixture (GPU box):
+    python scripts/profile_search_single.py            dense + BM25
+    python scripts/profile_search_single.py full       the reference's default: + ColBERT + rerank (stand-in CE)"""
 import cProfile
 import pstats
 import sys
@@ -13,6 +15,7 @@ sys.path.insert(0, str(ROOT))
 from legal_rag_amd.config import AppConfig  # noqa: E402
 from legal_rag_amd.evaluation import synthetic_queries  # noqa: E402
 from legal_rag_amd.retrieval.builders.bm25_builder import build_bm25_index  # noqa: E402
+from legal_rag_amd.retrieval.builders.colbert_builder import build_colbert_index  # noqa: E402
 from legal_rag_amd.retrieval.builders.faiss_builder import build_faiss_index  # noqa: E402
 from legal_rag_amd.retrieval.corpus_loader import load_chunks_from_dir  # noqa: E402
 from legal_rag_amd.retrieval.hybrid_retriever import HybridRetriever  # noqa: E402
@@ -22,10 +25,14 @@ with tempfile.TemporaryDirectory(prefix="amdr_prof_") as tmp:
     cfg.retrieval.encoder_backend = "hashing"
     cfg.retrieval.device = 0
     cfg.retrieval.enable_graph = False
-    cfg.retrieval.enable_colbert = cfg.retrieval.enable_rerank = False
+    full = len(sys.argv) > 1 and sys.argv[1] == "full"
+    cfg.retrieval.rerank_ce_model = "hashing"
+    cfg.retrieval.enable_colbert = cfg.retrieval.enable_rerank = full
     chunks = load_chunks_from_dir(str(ROOT / "tests" / "golden" / "corpus"), "law_en.jsonl")
     build_faiss_index(cfg, chunks)
     build_bm25_index(cfg, chunks)
+    if full:
+        build_colbert_index(cfg, chunks)
     qs = [q for q, _, _ in synthetic_queries(chunks, seed=0)]
     r = HybridRetriever(cfg)
     for q in qs[:30]:
