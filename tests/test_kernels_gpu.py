@@ -185,6 +185,19 @@ def test_dense_two_level_topk_equals_full_score_matrix(nat, monkeypatch):
             idx.close()
         assert np.array_equal(out["1"][1], out["0"][1]), (n, d, nq, k)
         assert np.array_equal(out["1"][0], out["0"][0]), (n, d, nq, k)
+    for _ in range(12):  # seeded sweep of shapes (the pinned form needs n >= 64 k rows)
+        k = int(rng.choice([1, 3, 10, 17, 40, 100]))
+        n = int(rng.integers(64 * k + 1, 64 * k + 30000))
+        d = int(rng.choice([64, 128, 320]))
+        nq = int(rng.integers(5, 96))
+        X, Q = unit_rows(rng, n, d), unit_rows(rng, nq, d)
+        out = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("AMDR_DENSE_TWO_LEVEL", flag)
+            idx = nat.DenseIndex(X)
+            out[flag] = idx.search(Q, k)
+            idx.close()
+        assert np.array_equal(out["1"][1], out["0"][1]) and np.array_equal(out["1"][0], out["0"][0]), (n, d, nq, k)
     monkeypatch.setenv("AMDR_DENSE_TWO_LEVEL", "1")
     check_dense(nat, unit_rows(rng, 4097, 192), unit_rows(rng, 17, 192), 10)
     base = unit_rows(rng, 700, 128)
