@@ -175,7 +175,9 @@ class HybridEngine:
         tensors (same nq; the BM25 term array may hold any number of terms up to its length).
         The "_device" entry points only enqueue and, after reserve(), allocate nothing
         (include/amdretrieval.h), which is what makes the step capturable.  A step of 4-5 short
-        kernels is launch-bound at small batch: replay removes the per-kernel launch gaps.
+        kernels is launch-bound at small batch: replay removes the per-kernel launch gaps.  (Measured: the BM25
+        channel on a forked branch of the captured graph — it does not depend on the dense channel — replays in
+        45 us against 33 us for the plain chain: the fork / join nodes cost more than the 5-us kernel they hide.)
         """
         nq = (q_emb.shape[0] if q_emb is not None else q_ptr.shape[0] - 1 if q_ptr is not None else q_tok.shape[0])
         self.reserve(int(nq), int(k), int(q_terms.numel()) if q_terms is not None else 0)
