@@ -12,7 +12,8 @@
  *
  * "_device" variants take DEVICE pointers and a hipStream_t passed as void*
  * (0 = the null stream); they enqueue work and return without synchronising,
- * and are graph-capturable once amdr_*_reserve() has sized the workspace.
+ * and are graph-capturable once amdr_*_reserve() has sized the workspace
+ * (reserve covers the "_device" workspace; the host-pointer calls size their own on first use).
  * A handle owns TWO workspaces: one for the "_device" calls, one for the plain
  * (host-pointer) calls.  "_device" calls on the same handle must be ordered with
  * respect to each other by the caller (same stream, or events between streams) —
@@ -84,6 +85,11 @@ int amdr_dense_read_rows(const amdr_dense_t* h, int64_t row0, int64_t nrows, flo
  * is cut (e.g. "dense_panel_scores_kernel nb=6 parts=7 blocks=2044 + scores_slab_topk_kernel"):
  * written NUL-terminated into buf.  No device work.  bench.py names its roofline kernel with it. */
 int amdr_dense_plan_info(const amdr_dense_t* h, int32_t nq, int32_t k, char* buf, int32_t buf_len);
+/* Host-only (no device is touched): workspace bytes a batched search of nq queries at depth k on an [n, d] matrix
+ * RESERVES before its passes — out6[0..2] = score / tile-maxima matrix, slab lists, candidate-tile lists — and the
+ * maximum any single pass (full chunks and the remainder) then USES — out6[3..5].  Zeros for the 1-4 query forms.
+ * A test holds out6[3+i] <= out6[i] over shapes with many row slabs (tests/test_abi.py). */
+int amdr_dense_workspace_plan(int64_t n, int32_t d, int32_t nq, int32_t k, int64_t* out6);
 /* HIP-event bracket around the scan kernel alone (not the merge), recorded on
  * the stream each search is launched on; used by bench.py for the roofline.
  * begin() arms up to max_launches event pairs, end() returns the summed scan

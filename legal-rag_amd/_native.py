@@ -30,7 +30,7 @@ EXPORTS = (
     "amdr_last_error", "amdr_version", "amdr_device_count", "amdr_device_name",
     "amdr_dense_create", "amdr_dense_create_from_device", "amdr_dense_add", "amdr_dense_ntotal", "amdr_dense_dim",
     "amdr_dense_reserve", "amdr_dense_search", "amdr_dense_search_device", "amdr_dense_read_rows", "amdr_dense_score_rows",
-    "amdr_dense_plan_info", "amdr_dense_profile_begin", "amdr_dense_profile_end", "amdr_dense_destroy",
+    "amdr_dense_plan_info", "amdr_dense_workspace_plan", "amdr_dense_profile_begin", "amdr_dense_profile_end", "amdr_dense_destroy",
     "amdr_bm25_create", "amdr_bm25_ndocs", "amdr_bm25_reserve", "amdr_bm25_search", "amdr_bm25_search_device",
     "amdr_bm25_scores", "amdr_bm25_destroy",
     "amdr_maxsim_create", "amdr_maxsim_ndocs", "amdr_maxsim_reserve", "amdr_maxsim_search",
@@ -49,7 +49,7 @@ SIGNATURES = {
     "amdr_dense_create": "PliiP", "amdr_dense_create_from_device": "PliiP", "amdr_dense_add": "PPl",
     "amdr_dense_ntotal": "PP", "amdr_dense_dim": "PP", "amdr_dense_reserve": "Pii", "amdr_dense_search": "PPiiPP",
     "amdr_dense_search_device": "PPiiPPP", "amdr_dense_read_rows": "PllP", "amdr_dense_score_rows": "PPiPiP",
-    "amdr_dense_plan_info": "PiiPi", "amdr_dense_profile_begin": "Pi", "amdr_dense_profile_end": "PPP", "amdr_dense_destroy": "P",
+    "amdr_dense_plan_info": "PiiPi", "amdr_dense_workspace_plan": "liiiP", "amdr_dense_profile_begin": "Pi", "amdr_dense_profile_end": "PPP", "amdr_dense_destroy": "P",
     "amdr_bm25_create": "PPPPPlldddiP", "amdr_bm25_ndocs": "PP", "amdr_bm25_reserve": "Piil",
     "amdr_bm25_search": "PPPiiPP", "amdr_bm25_search_device": "PPPiiPPP", "amdr_bm25_scores": "PPPiP",
     "amdr_bm25_destroy": "P",
@@ -128,6 +128,15 @@ def device_name(device: int = 0) -> str:
     buf = C.create_string_buffer(256)
     _check(load().amdr_device_name(C.c_int32(device), buf, C.c_int32(256)), "amdr_device_name")
     return buf.value.decode()
+
+
+def dense_workspace_plan(n: int, d: int, nq: int, k: int) -> Tuple[Tuple[int, int, int], Tuple[int, int, int]]:
+    """(reserved, used by the largest pass) workspace bytes of one batched dense search — host-only arithmetic."""
+    out = (C.c_int64 * 6)()
+    _check(load().amdr_dense_workspace_plan(C.c_int64(n), C.c_int32(d), C.c_int32(nq), C.c_int32(k), out),
+           "amdr_dense_workspace_plan")
+    v = [int(x) for x in out]
+    return tuple(v[:3]), tuple(v[3:])
 
 
 def _p(a: Optional[np.ndarray], ctype):

@@ -88,7 +88,7 @@ int dense_mfma_launch_scores(const DenseMfmaPlan& p, const float* X, long n, int
                              const int* tile_count = nullptr, long n_real = 0);
 // two-level top-k helpers: sorted unique list of the candidate tiles; column -> row id of the final hits
 int dense_tiles_unique_launch(const int64_t* tile_ids, int n_in, int* list, int* count, hipStream_t st);
-int dense_tiles_remap_launch(int64_t* ids, int total, const int* list, hipStream_t st);
+int dense_tiles_remap_launch(int64_t* ids, int total, const int* list, const int* count, long n_real, hipStream_t st);
 int dense_mfma_launch_topk(const DenseMfmaPlan& p, const float* S, long n, int nq, int k, void* part,
                            float* fin_scores, int64_t* fin_ids, hipStream_t st);
 

@@ -397,6 +397,20 @@ int batched_chunk(const amdr_dense* h, int nq) {
   return nq < c ? nq : (int)c;
 }
 
+// Slab-list bytes of one batched search: the full chunk AND the remainder pass (planned for its own size:
+// slabs(m) * m is not monotone in m, so a shorter pass can need more).
+size_t batched_part_need(const amdr_dense* h, int nq, int k) {
+  const int chunk = batched_chunk(h, nq);
+  DenseMfmaPlan p;
+  dense_mfma_plan((long)h->n, h->d, chunk, k, &p);
+  size_t need = p.part_bytes;
+  if (nq % chunk) {
+    dense_mfma_plan((long)h->n, h->d, nq % chunk, k, &p);
+    need = p.part_bytes > need ? p.part_bytes : need;
+  }
+  return need;
+}
+
 // Two-pass form: scores S[q][row] (fp32-MFMA tiles for batches, one wave per (query, row) for the
 // 1-4 query call on a short corpus), then slab top-k (+ merge when there are several slabs).
 int run_search_batched(amdr_dense* h, int ws, const float* Q_dev, int nq, int k, float* scores_dev, int64_t* ids_dev,
@@ -407,7 +421,7 @@ int run_search_batched(amdr_dense* h, int ws, const float* Q_dev, int nq, int k,
   DenseMfmaPlan p;
   dense_mfma_plan((long)h->n, h->d, chunk, k, &p);
   int rc = smat.ensure(p.s_bytes);
-  if (!rc) rc = partb.ensure(p.part_bytes);
+  if (!rc) rc = partb.ensure(batched_part_need(h, nq, k));
   if (rc) return rc;
   for (int q0 = 0; q0 < nq; q0 += chunk) {
     const int m = nq - q0 < chunk ? nq - q0 : chunk;
@@ -489,20 +503,49 @@ void two_level_plan(const amdr_dense* h, int m, int k, TwoLevelPlan* t) {
   t->aux_bytes = (size_t)m * k * (sizeof(int64_t) + sizeof(float)) + (size_t)(m * k + 64) * sizeof(int) + 256;
   t->part_bytes = t->tk1.part_bytes > t->pass2.part_bytes ? t->tk1.part_bytes : t->pass2.part_bytes;
 }
-// Workspace for (nq, k); with all_k for every k' <= k as well — a smaller k takes MORE queries per pass, i.e. a larger
-// matrix of tile maxima, and amdr_dense_reserve promises that calls within (nq_max, k_max) allocate nothing.
-int two_level_ensure(amdr_dense* h, int ws, int nq, int k, bool all_k = false) {
+// Workspace for one search of nq queries at depth k: the maximum over every chunk size the pass loop will use — the
+// full chunk AND the remainder (a smaller chunk can need MORE slab-list space: slabs(m) * m is not monotone in m).
+// With `all` (amdr_dense_reserve: calls within (nq_max, k_max) must allocate nothing) the maximum over every batch
+// size <= nq and every depth <= k that takes this path — a smaller k takes more queries per pass (a larger matrix of
+// tile maxima) and the path's own applicability test depends on k.
+struct TwoLevelNeed {
   size_t smat = 0, part = 0, aux = 0;
-  for (int kk = all_k ? 1 : k; kk <= k; ++kk) {
-    TwoLevelPlan t;
-    two_level_plan(h, two_level_chunk(nq, kk), kk, &t);
+  void add(const TwoLevelPlan& t) {
     smat = t.m_bytes + t.s2_bytes > smat ? t.m_bytes + t.s2_bytes : smat;
     part = t.part_bytes > part ? t.part_bytes : part;
     aux = t.aux_bytes > aux ? t.aux_bytes : aux;
   }
-  int rc = h->smat[ws].ensure(smat);
-  if (!rc) rc = h->part[ws].ensure(part);
-  if (!rc) rc = h->aux[ws].ensure(aux);
+};
+void two_level_need(const amdr_dense* h, int nq, int k, TwoLevelNeed* need) {
+  const int chunk = two_level_chunk(nq, k);
+  TwoLevelPlan t;
+  two_level_plan(h, chunk, k, &t);
+  need->add(t);
+  if (nq % chunk) {
+    two_level_plan(h, nq % chunk, k, &t);
+    need->add(t);
+  }
+}
+int two_level_ensure(amdr_dense* h, int ws, int nq, int k, bool all = false) {
+  TwoLevelNeed need;
+  if (!all) {
+    two_level_need(h, nq, k, &need);
+  } else {
+    for (int kk = 1; kk <= k; ++kk) {
+      // a call's path is chosen on its whole batch; its passes (full chunks and a remainder of ANY size) then
+      // all run the two-level form: cover every m a pass can have
+      if (!two_level_applies(h, nq < 95 ? nq : 95, kk) && !two_level_applies(h, nq, kk)) continue;
+      const int cmax = two_level_chunk(nq, kk);
+      TwoLevelPlan t;
+      for (int m = 1; m <= cmax; ++m) {
+        two_level_plan(h, m, kk, &t);
+        need.add(t);
+      }
+    }
+  }
+  int rc = need.smat ? h->smat[ws].ensure(need.smat) : AMDR_OK;
+  if (!rc && need.part) rc = h->part[ws].ensure(need.part);
+  if (!rc && need.aux) rc = h->aux[ws].ensure(need.aux);
   return rc;
 }
 
@@ -558,7 +601,7 @@ int run_search_two_level(amdr_dense* h, int ws, const float* Q_dev, int nq, int 
     if ((rc = topk_pass(t.pass2, S2, t.cand_rows, m, k, h->part[ws], scores_dev + (size_t)q0 * k, ids_dev + (size_t)q0 * k,
                         st)))
       return rc;
-    if ((rc = dense_tiles_remap_launch(ids_dev + (size_t)q0 * k, m * k, list, st))) return rc;
+    if ((rc = dense_tiles_remap_launch(ids_dev + (size_t)q0 * k, m * k, list, count, (long)h->n, st))) return rc;
   }
   return AMDR_OK;
 }
@@ -708,17 +751,21 @@ int amdr_dense_reserve(amdr_dense_t* h, int32_t nq_max, int32_t k_max) {
   make_plan(h->n, h->d, nq_max, k_max, &p);
   int rc = h->part[0].ensure(p.part_bytes);
   if (rc) return rc;
-  // batches of 5-95 queries on a large matrix take the two-level form, longer ones the panel kernel + score matrix
-  const int nq_two = nq_max < 95 ? nq_max : 95;
-  if (two_level_applies(h, nq_two, k_max)) {
-    if ((rc = two_level_ensure(h, 0, nq_two, k_max, true))) return rc;
-  }
+  // batches on a large matrix take the two-level form (every batch size <= nq_max and depth <= k_max that does is
+  // covered, see two_level_ensure); longer ones the panel kernel + score matrix
+  if ((rc = two_level_ensure(h, 0, nq_max, k_max, true))) return rc;
   if (two_level_applies(h, nq_max, k_max)) {
   } else if (nq_max >= kBatchedMin && h->n > 0 && dense_mfma_supported(h->d)) {
     DenseMfmaPlan mp;
-    dense_mfma_plan((long)h->n, h->d, batched_chunk(h, nq_max), k_max, &mp);
+    const int cmax = batched_chunk(h, nq_max);
+    dense_mfma_plan((long)h->n, h->d, cmax, k_max, &mp);
     if ((rc = h->smat[0].ensure(mp.s_bytes))) return rc;
-    if ((rc = h->part[0].ensure(mp.part_bytes))) return rc;
+    size_t part_need = 0;  // every pass size a call within nq_max can have (slab lists: not monotone in the size)
+    for (int m = 1; m <= cmax; ++m) {
+      dense_mfma_plan((long)h->n, h->d, m, k_max, &mp);
+      part_need = mp.part_bytes > part_need ? mp.part_bytes : part_need;
+    }
+    if ((rc = h->part[0].ensure(part_need))) return rc;
   }
   if (h->n > 0 && h->n <= kRowWavesMax) {  // the 1-4 query call on a short corpus also goes through S
     DenseMfmaPlan mp;
@@ -791,6 +838,38 @@ int amdr_dense_read_rows(const amdr_dense_t* h, int64_t row0, int64_t nrows, flo
   if (nrows)
     AMDR_HIP(hipMemcpy(out_host, h->X + (size_t)row0 * h->d, (size_t)nrows * h->d * sizeof(float),
                        hipMemcpyDeviceToHost));
+  return AMDR_OK;
+}
+
+int amdr_dense_workspace_plan(int64_t n, int32_t d, int32_t nq, int32_t k, int64_t* out6) {
+  AMDR_REQUIRE(out6 != nullptr, "dense_workspace_plan: null");
+  AMDR_REQUIRE(n >= 1 && n < (1ll << 32) && d >= 4 && d <= AMDR_MAX_DIM && d % 4 == 0, "dense_workspace_plan: bad shape");
+  AMDR_REQUIRE(nq >= 1 && k >= 1 && k <= AMDR_MAX_K, "dense_workspace_plan: bad sizes");
+  amdr_dense h;  // shape only: no device is touched
+  h.n = n;
+  h.d = d;
+  for (int i = 0; i < 6; ++i) out6[i] = 0;
+  auto mx = [](int64_t& a, size_t b) { a = (int64_t)b > a ? (int64_t)b : a; };
+  if (two_level_applies(&h, nq, k)) {
+    TwoLevelNeed need;
+    two_level_need(&h, nq, k, &need);
+    out6[0] = (int64_t)need.smat, out6[1] = (int64_t)need.part, out6[2] = (int64_t)need.aux;
+    const int chunk = two_level_chunk(nq, k);
+    for (int q0 = 0; q0 < nq; q0 += chunk) {
+      TwoLevelPlan t;
+      two_level_plan(&h, nq - q0 < chunk ? nq - q0 : chunk, k, &t);
+      mx(out6[3], t.m_bytes + t.s2_bytes), mx(out6[4], t.part_bytes), mx(out6[5], t.aux_bytes);
+    }
+  } else if (nq >= kBatchedMin && dense_mfma_supported(d)) {
+    const int chunk = batched_chunk(&h, nq);
+    DenseMfmaPlan p;
+    dense_mfma_plan((long)n, d, chunk, k, &p);
+    out6[0] = (int64_t)p.s_bytes, out6[1] = (int64_t)batched_part_need(&h, nq, k);
+    for (int q0 = 0; q0 < nq; q0 += chunk) {
+      dense_mfma_plan((long)n, d, nq - q0 < chunk ? nq - q0 : chunk, k, &p);
+      mx(out6[3], p.s_bytes), mx(out6[4], p.part_bytes);
+    }
+  }
   return AMDR_OK;
 }
 

@@ -526,11 +526,19 @@ __global__ __launch_bounds__(64) void tiles_unique_kernel(const long long* __res
 // step 4: the final hits carry COLUMNS of the re-scored candidate matrix (32 per list entry); columns ascend with the
 // row ids (the list is ascending), so ties were already broken towards the lower id.
 __global__ __launch_bounds__(256) void tiles_remap_ids_kernel(long long* __restrict__ ids, int total,
-                                                              const int* __restrict__ list) {
+                                                              const int* __restrict__ list,
+                                                              const int* __restrict__ count, long n_real) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < total) {
     const long long c = ids[i];
-    if (c >= 0) ids[i] = (long long)list[c >> 5] * 32 + (c & 31);
+    if (c >= 0) {
+      // a filler column (beyond the candidate list, or past the end of the matrix inside the last tile: score
+      // -FLT_MAX) reaches the final list only when fewer than k candidate rows have a real (non-NaN) score: it is
+      // padding, id -1 (the faiss convention for "fewer than k results"), never a read of an unwritten list entry
+      const long long t = c >> 5;
+      const long long r = t < *count ? (long long)list[t] * 32 + (c & 31) : -1;
+      ids[i] = r < n_real ? r : -1;
+    }
   }
 }
 
@@ -542,8 +550,9 @@ int dense_tiles_unique_launch(const int64_t* tile_ids, int n_in, int* list, int*
   AMDR_HIP(hipGetLastError());
   return AMDR_OK;
 }
-int dense_tiles_remap_launch(int64_t* ids, int total, const int* list, hipStream_t st) {
-  hipLaunchKernelGGL(tiles_remap_ids_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, (long long*)ids, total, list);
+int dense_tiles_remap_launch(int64_t* ids, int total, const int* list, const int* count, long n_real, hipStream_t st) {
+  hipLaunchKernelGGL(tiles_remap_ids_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, (long long*)ids, total, list,
+                     count, n_real);
   AMDR_HIP(hipGetLastError());
   return AMDR_OK;
 }

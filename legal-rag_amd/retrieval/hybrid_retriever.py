@@ -290,20 +290,26 @@ class HybridRetriever:
                                     source="retriever", score_breakdown=sb))
         return out
 
+    def _eff_depth(self, top_k: int, who: str) -> int:
+        """Per-channel depth max(cfg.retrieval.top_k, top_k) (hybrid_retriever.py:289-292).  Beyond the fusion
+        kernel's limit search(), search_batch() and search_batch_arrays() all refuse with ONE clear error — no
+        NativeError from one channel, fallback in another and silent clamp in a third, and no host-side fuse
+        (the product has no CPU path); the per-channel searches themselves accept any depth."""
+        rcfg = self.cfg.retrieval
+        eff = int(getattr(rcfg, "top_k", top_k * 8) or (top_k * 8))
+        eff = max(eff, top_k)
+        if eff > _native.MAX_K:
+            raise ValueError(f"HybridRetriever.{who}: per-channel depth {eff} (max(cfg.retrieval.top_k, top_k)) "
+                             f"exceeds the fusion kernel's limit of {_native.MAX_K} hits per channel")
+        return eff
+
     # ---------------------------------------------------------- main search
     def search(self, question: str, llm: Any = None, top_k: int = 10, decision: Any = None) -> List[RetrievalHit]:
         rcfg = self.cfg.retrieval
         top_k = max(1, int(top_k))
         has_gpu = _native.device_count() > 0
         t_start = time.time()
-        eff_top_k = int(getattr(rcfg, "top_k", top_k * 8) or (top_k * 8))
-        if eff_top_k < top_k:
-            eff_top_k = top_k
-        if eff_top_k > _native.MAX_K:
-            # ONE clear error for every channel instead of a NativeError from one, a fallback in another and a
-            # silent clamp in the third (the per-channel searches themselves accept any depth)
-            raise ValueError(f"HybridRetriever.search: per-channel depth {eff_top_k} (max(cfg.retrieval.top_k, top_k)) "
-                             f"exceeds the fusion kernel's limit of {_native.MAX_K} hits per channel")
+        eff_top_k = self._eff_depth(top_k, "search")
 
         min_final = float(getattr(rcfg, "min_final_score", 0.0))
         native = self._native_channels(eff_top_k)
@@ -491,9 +497,18 @@ class HybridRetriever:
             qbuf = torch.from_numpy(np.concatenate([qp8, qt8])).to(tdev, non_blocking=True)
             q_ptr_d = qbuf[: qp8.size].view(torch.int64)
             q_terms_d = qbuf[qp8.size:].view(torch.int32) if qt8.size else torch.zeros(1, dtype=torch.int32, device=tdev)
-            res = eng.search_batch(self._params(kn, min_final), eff,
-                                   q_emb=q_emb, q_terms=q_terms_d, q_ptr=q_ptr_d,
-                                   q_tok=torch.from_numpy(q_tok_h).to(tdev, non_blocking=True) if q_tok_h is not None else None)
+            try:
+                res = eng.search_batch(self._params(kn, min_final), eff, q_emb=q_emb, q_terms=q_terms_d, q_ptr=q_ptr_d,
+                                       q_tok=torch.from_numpy(q_tok_h).to(tdev, non_blocking=True) if q_tok_h is not None else None)
+            except _native.NativeError:
+                if col is None:
+                    raise
+                # a failing ColBERT stage (e.g. out of memory) empties that channel, it does not fail the query
+                # (hybrid_retriever.py:244-245, colbert_retriever.py:171-181); a dense / BM25 failure raises again here
+                eng = engines.get(False)
+                if eng is None:
+                    eng = engines[False] = HybridEngine(store.index.native, bm.bm25.gpu(dev), None, device=dev)
+                res = eng.search_batch(self._params(kn, min_final), eff, q_emb=q_emb, q_terms=q_terms_d, q_ptr=q_ptr_d)
             # ONE synchronise and ONE device-to-host copy (the four outputs share an allocation)
             ids, vals, mask, cnt = res.to_host()
         if arrays:
@@ -515,8 +530,7 @@ class HybridRetriever:
         whole batch (dense + BM25 (+ ColBERT) -> fuse -> filter), results built once."""
         rcfg = self.cfg.retrieval
         top_k = max(1, int(top_k))
-        eff = int(getattr(rcfg, "top_k", top_k * 8) or (top_k * 8))
-        eff = min(max(eff, top_k), _native.MAX_K)
+        eff = self._eff_depth(top_k, "search_batch")
         native = self._native_channels(eff)
         if native is None:
             raise RuntimeError("search_batch requires this package's own dense / BM25 (/ ColBERT) retrievers built "
@@ -531,8 +545,7 @@ class HybridRetriever:
         The rows of one index are distinct chunks, so the dedup step of search() has nothing to merge."""
         rcfg = self.cfg.retrieval
         top_k = max(1, int(top_k))
-        eff = int(getattr(rcfg, "top_k", top_k * 8) or (top_k * 8))
-        eff = min(max(eff, top_k), _native.MAX_K)
+        eff = self._eff_depth(top_k, "search_batch_arrays")
         native = self._native_channels(eff)
         if native is None:
             raise RuntimeError("search_batch_arrays requires this package's own retrievers built over the same chunk list")

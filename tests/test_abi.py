@@ -85,3 +85,24 @@ def test_no_cpu_fallback_in_product():
     for py in pkg.rglob("*.py"):
         txt = py.read_text(encoding="utf-8")
         assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f"{py} imports the oracle"
+
+
+def test_dense_workspace_covers_every_pass(monkeypatch):
+    """A batched dense search reserves its workspace once and then runs passes of the full chunk and a remainder:
+    the slab-list space slabs(m) * m * k * 8 is NOT monotone in the pass size m (13 M rows, k = 10: 96 queries take
+    22 slabs = 168 960 B, the 89-query remainder 24 slabs = 170 880 B), so the reservation must be the maximum over
+    the passes.  Host-only arithmetic (amdr_dense_workspace_plan): no device."""
+    from legal_rag_amd import _native
+    checked = two_level = 0
+    for n in (13_000_000, 12_345_678, 20_000_000, 40_000_000, 3_000_000, 600_000):
+        for k in (1, 10, 80, 256):
+            for nq in (5, 37, 95, 96, 97, 100, 131, 185, 191, 192, 193, 250, 1000):
+                res, used = _native.dense_workspace_plan(n, 768, nq, k)
+                assert all(u <= r for u, r in zip(used, res)), (n, k, nq, res, used)
+                checked += 1
+                two_level += int(res[2] > 0)
+    assert checked > 300 and two_level > 50
+    # the advisor's worked example, pinned: remainder 89 needs more list space than the chunk of 96
+    monkeypatch.setenv("AMDR_DENSE_TWO_LEVEL", "1")
+    res, used = _native.dense_workspace_plan(13_000_000, 768, 185, 10)
+    assert used[1] == 170880 and res[1] >= used[1]

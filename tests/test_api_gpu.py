@@ -461,6 +461,9 @@ def test_depth_beyond_kernel_limit_is_handled_uniformly(ucc_index):
         assert all(a.score >= b.score for a, b in zip(deep, deep[1:]))
     with pytest.raises(ValueError, match="exceeds the fusion kernel"):
         r.search(q, top_k=300)
+    for batch_form in (r.search_batch, r.search_batch_arrays):  # the batch forms refuse the same way (no silent clamp)
+        with pytest.raises(ValueError, match="exceeds the fusion kernel"):
+            batch_form([q], top_k=300)
     big = [h for h in r.search_dense(q, 200)] * 2
     with pytest.raises(ValueError, match="exceed the fusion kernel"):
         r._fuse(dense_hits=big, bm25_hits=[], colbert_hits=[])
