@@ -124,6 +124,9 @@ class HashingCrossScorer:
     def score(self, query: str, doc: str) -> float:
         return self.score_batch(query, [doc])[0]
 
+    def score_pairs(self, pairs) -> List[float]:
+        return [self.score_batch(q, [d])[0] for q, d in pairs]
+
 
 class TransformersBGE:
     """BGE sentence encoder on PyTorch-ROCm (plain transformers; FlagModel recipe)."""

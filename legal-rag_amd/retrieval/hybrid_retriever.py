@@ -347,22 +347,7 @@ class HybridRetriever:
 
         t_rerank = None
         if getattr(rcfg, "enable_rerank", False):
-            use_llm_rerank = bool(getattr(rcfg, "rerank_use_llm", False))
-            dev = getattr(rcfg, "device", None)
-            factory = RerankerFactory(llm=llm if use_llm_rerank else None, cross_model=rcfg.rerank_ce_model,
-                                      llm_threshold=30, use_cache=True,
-                                      device=None if dev is None else (dev if isinstance(dev, str) else f"cuda:{int(dev)}"),
-                                      fp16=bool(getattr(rcfg, "rerank_fp16", False)))
-            rerank_top_n = int(getattr(rcfg, "rerank_top_n", min(40, max(10, top_k * 4))))
-            beta = float(getattr(rcfg, "rerank_beta", 0.35))
-            cand = fused[:rerank_top_n]
-            if cand:
-                reranker = factory.create(top_k=len(cand))
-                # the reference hands the hit objects to rerank_candidates, whose
-                # _to_doc_text turns them into str(hit) (rerankers.py:78-86) — kept.
-                docs = [_to_doc_text(h) for h in cand]
-                raw = [float(x) for x in reranker.score_batch(question, docs)]
-                fused = self._rerank_blend(fused, raw, beta)
+            fused = self._rerank_stage([question], [fused], llm, top_k)[0]
             t_rerank = time.time()
 
         fused = _dedup_keep_best(fused)
@@ -378,29 +363,93 @@ class HybridRetriever:
             int(bool(getattr(rcfg, "enable_graph", False))), int(self.colbert is not None), int(has_gpu))
         return fused[:top_k]
 
+    def _rerank_stage(self, questions: Sequence[str], fused_lists: List[List[RetrievalHit]], llm: Any,
+                      top_k: int) -> List[List[RetrievalHit]]:
+        """hybrid_retriever.py:324-356 for one or many queries: the first rerank_top_n fused hits of each query are
+        scored by the reranker (cross-encoder unless an LLM judge is configured and the list is short,
+        rerankers.py:301-312), the scores normalised, blended and the lists re-ranked — the scoring of ALL queries'
+        candidates goes through the model in full batches (`score_pairs`), the blend of all queries is ONE
+        amdr_rerank_blend launch."""
+        rcfg = self.cfg.retrieval
+        use_llm_rerank = bool(getattr(rcfg, "rerank_use_llm", False))
+        dev = getattr(rcfg, "device", None)
+        factory = RerankerFactory(llm=llm if use_llm_rerank else None, cross_model=rcfg.rerank_ce_model,
+                                  llm_threshold=30, use_cache=True,
+                                  device=None if dev is None else (dev if isinstance(dev, str) else f"cuda:{int(dev)}"),
+                                  fp16=bool(getattr(rcfg, "rerank_fp16", False)))
+        rerank_top_n = int(getattr(rcfg, "rerank_top_n", min(40, max(10, top_k * 4))))
+        beta = float(getattr(rcfg, "rerank_beta", 0.35))
+        # the reference hands the hit objects to rerank_candidates, whose _to_doc_text turns them into str(hit)
+        # (rerankers.py:78-86) — kept.
+        jobs = []  # (query index, reranker, docs)
+        for qi, fused in enumerate(fused_lists):
+            cand = fused[:rerank_top_n]
+            if cand:
+                jobs.append((qi, factory.create(top_k=len(cand)), [_to_doc_text(h) for h in cand]))
+        raws: Dict[int, List[float]] = {}
+        by_model: Dict[int, List[int]] = {}
+        for j, (_, rr, _) in enumerate(jobs):
+            by_model.setdefault(id(rr), []).append(j)
+        for group in by_model.values():
+            rr = jobs[group[0]][1]
+            if len(group) > 1 and hasattr(rr, "score_pairs"):
+                pairs = [(questions[jobs[j][0]], d) for j in group for d in jobs[j][2]]
+                flat = [float(x) for x in rr.score_pairs(pairs)]
+                at = 0
+                for j in group:
+                    n = len(jobs[j][2])
+                    raws[jobs[j][0]] = flat[at:at + n]
+                    at += n
+            else:
+                for j in group:
+                    qi, _, docs = jobs[j]
+                    raws[qi] = [float(x) for x in rr.score_batch(questions[qi], docs)]
+        todo = [qi for qi in range(len(fused_lists)) if qi in raws]
+        if todo:
+            blended = self._rerank_blend_many([fused_lists[qi] for qi in todo], [raws[qi] for qi in todo], beta)
+            fused_lists = list(fused_lists)
+            for qi, hits in zip(todo, blended):
+                fused_lists[qi] = hits
+        return fused_lists
+
     @staticmethod
     def _rerank_blend(fused: List[RetrievalHit], raw: List[float], beta: float) -> List[RetrievalHit]:
-        """hybrid_retriever.py:343-355 on the GPU: normalise the cross-encoder
-        scores, blend, re-rank.  `raw[j]` belongs to fused[j]."""
-        n = len(fused)
-        ids = np.arange(n, dtype=np.int64)[None, :].copy()
-        vals = np.zeros((1, n, _native.FUSE_NVALS), dtype=np.float64)
-        vals[0, :, 0] = [float(h.score) for h in fused]
-        mask = np.zeros((1, n), dtype=np.int32)
-        count = np.asarray([n], dtype=np.int32)
-        rr = _native.rerank_blend(count, ids, vals, mask, np.asarray([raw], dtype=np.float64), float(beta))
-        out: List[RetrievalHit] = []
-        for r in range(n):
-            h = fused[int(ids[0, r])]
-            h.score = float(vals[0, r, 0])
-            h.rank = r + 1
-            if not math.isnan(rr[0, r, 0]):
-                h.score_breakdown = h.score_breakdown or {}
-                h.score_breakdown.update({"rerank_raw": float(rr[0, r, 0]), "rerank_norm": float(rr[0, r, 1]),
-                                          "rerank_beta": beta})
-                h.source = "rerank"
-            out.append(h)
-        return out
+        return HybridRetriever._rerank_blend_many([fused], [raw], beta)[0]
+
+    @staticmethod
+    def _rerank_blend_many(lists: List[List[RetrievalHit]], raws: List[List[float]], beta: float) -> List[List[RetrievalHit]]:
+        """hybrid_retriever.py:343-355 on the GPU for a batch of queries in one launch: normalise the cross-encoder
+        scores, blend, re-rank.  `raws[q][j]` belongs to lists[q][j]."""
+        nq = len(lists)
+        n = max(len(f) for f in lists)
+        top_n = max(len(r) for r in raws)
+        ids = np.full((nq, n), -1, dtype=np.int64)
+        vals = np.zeros((nq, n, _native.FUSE_NVALS), dtype=np.float64)
+        mask = np.zeros((nq, n), dtype=np.int32)
+        count = np.zeros(nq, dtype=np.int32)
+        ce = np.zeros((nq, top_n), dtype=np.float64)
+        for q, (fused, raw) in enumerate(zip(lists, raws)):
+            m = len(fused)
+            ids[q, :m] = np.arange(m)
+            vals[q, :m, 0] = [float(h.score) for h in fused]
+            count[q] = m
+            ce[q, :len(raw)] = raw
+        rr = _native.rerank_blend(count, ids, vals, mask, ce, float(beta))
+        outs: List[List[RetrievalHit]] = []
+        for q, fused in enumerate(lists):
+            out: List[RetrievalHit] = []
+            for r in range(len(fused)):
+                h = fused[int(ids[q, r])]
+                h.score = float(vals[q, r, 0])
+                h.rank = r + 1
+                if not math.isnan(rr[q, r, 0]):
+                    h.score_breakdown = h.score_breakdown or {}
+                    h.score_breakdown.update({"rerank_raw": float(rr[q, r, 0]), "rerank_norm": float(rr[q, r, 1]),
+                                              "rerank_beta": beta})
+                    h.source = "rerank"
+                out.append(h)
+            outs.append(out)
+        return outs
 
     # ------------------------------------------------- device-resident stage
     def _native_channels(self, eff: int):
@@ -525,17 +574,31 @@ class HybridRetriever:
         return out, (t1, t2, t3)
 
     # ----------------------------------------------------------- batch form
-    def search_batch(self, questions: Sequence[str], top_k: int = 10) -> List[List[RetrievalHit]]:
-        """Throughput form of `search` without rerank: one kernel pipeline for the
-        whole batch (dense + BM25 (+ ColBERT) -> fuse -> filter), results built once."""
+    def search_batch(self, questions: Sequence[str], top_k: int = 10, llm: Any = None,
+                     decisions: Optional[Sequence[Any]] = None) -> List[List[RetrievalHit]]:
+        """Throughput form: `search_batch(qs)[i]` == `search(qs[i])` for every stage the configuration enables
+        (hybrid_retriever.py:282-384) — one kernel pipeline for the whole batch (dense + BM25 (+ ColBERT) -> fuse
+        -> filter), the graph stage per query whose `decisions[i]` asks for it, the rerank stage with the
+        cross-encoder fed in full batches over all queries' candidates and ONE blend launch, dedup, cut."""
         rcfg = self.cfg.retrieval
         top_k = max(1, int(top_k))
+        questions = list(questions)
+        if decisions is not None and len(decisions) != len(questions):
+            raise ValueError("search_batch: decisions must have one entry per question")
         eff = self._eff_depth(top_k, "search_batch")
         native = self._native_channels(eff)
         if native is None:
             raise RuntimeError("search_batch requires this package's own dense / BM25 (/ ColBERT) retrievers built "
                                "over the same chunk list")
-        outs, _ = self._batch_native(list(questions), eff, native, float(getattr(rcfg, "min_final_score", 0.0)))
+        outs, _ = self._batch_native(questions, eff, native, float(getattr(rcfg, "min_final_score", 0.0)))
+        if getattr(rcfg, "enable_graph", False) and decisions is not None:
+            seed_n = int(getattr(rcfg, "graph_seed_k", max(10, top_k * 3)))
+            for i, dec in enumerate(decisions):
+                if _is_graph_mode(getattr(dec, "mode", None)):
+                    seeds = outs[i][:seed_n]
+                    outs[i] = seeds + self.search_graph(questions[i], eff, decision=dec, seeds=seeds)
+        if getattr(rcfg, "enable_rerank", False):
+            outs = self._rerank_stage(questions, outs, llm, top_k)
         return [_dedup_keep_best(hits)[:top_k] for hits in outs]
 
     def search_batch_arrays(self, questions: Sequence[str], top_k: int = 10) -> Dict[str, Any]:

@@ -124,6 +124,20 @@ class CrossEncoderReranker:
     def score(self, query: str, doc: str) -> float:
         return self.score_batch(query, [doc])[0]
 
+    def score_pairs(self, pairs: Sequence[Tuple[str, str]]) -> List[float]:
+        """(query, doc) pairs of SEVERAL queries through the model in full batches — the batched form behind
+        HybridRetriever.search_batch (one forward per `batch_size` pairs instead of one short batch per query)."""
+        torch, out = self._torch, []
+        with torch.inference_mode():
+            for lo in range(0, len(pairs), self.batch_size):
+                part = pairs[lo:lo + self.batch_size]
+                enc = self._tok([q for q, _ in part], [d for _, d in part], padding=True, truncation=True,
+                                max_length=self.max_length, return_tensors="pt").to(self._device)
+                logits = self._model(**enc).logits.float()
+                vals = torch.sigmoid(logits[:, 0]) if logits.shape[-1] == 1 else logits[:, -1]
+                out += [float(v) for v in vals.cpu()]
+        return out
+
 
 # ------------------------------------------------------------------ LLM judges
 LLM_RERANK_SYSTEM_PROMPT = (

@@ -243,6 +243,108 @@ def test_search_batch_equals_single_queries(ucc_index):
                 assert abs(gb["channel_contrib"][ch] - eb["channel_contrib"][ch]) <= 2e-5
 
 
+class IdReranker:
+    """Cross-encoder stand-in whose score depends on (query, chunk id) only — the repr of a hit carries its fused
+    score to the last digit, and a batch takes a different dense kernel form than a single query (rounding-level
+    differences), so a text-hashing stand-in would jitter between the two paths."""
+
+    def __init__(self):
+        self.pair_calls = self.batch_calls = 0
+
+    @staticmethod
+    def _s(query, doc):
+        import hashlib
+        import re
+        cid = re.search(r"LawChunk\(id='([^']+)'", doc).group(1)
+        return int.from_bytes(hashlib.blake2b((query + "\0" + cid).encode(), digest_size=4).digest(), "little") / 2**32
+
+    def score_batch(self, query, docs):
+        self.batch_calls += 1
+        return [self._s(query, d) for d in docs]
+
+    def score_pairs(self, pairs):
+        self.pair_calls += 1
+        return [self._s(q, d) for q, d in pairs]
+
+
+def test_search_batch_with_rerank_equals_single_queries(ucc_index, monkeypatch):
+    """The reference's default configuration (ColBERT ON, rerank ON, config.py:97,119): search_batch(qs)[i] ==
+    search(qs[i]) — the batch form runs the rerank stage too (cross-encoder fed over all queries' candidates in one
+    score_pairs call, ONE blend launch), it no longer drops it (hybrid_retriever.py:324-356)."""
+    from legal_rag_amd.retrieval import hybrid_retriever as hr
+    cfg, _ = ucc_index
+    cfg2 = copy.deepcopy(cfg)
+    assert cfg2.retrieval.enable_rerank and cfg2.retrieval.enable_colbert
+    ce = IdReranker()
+    monkeypatch.setattr(hr.RerankerFactory, "create", lambda self, top_k: ce)
+    r = hr.HybridRetriever(cfg2)
+    qs = QUESTIONS + ["", "zzzz qqqq", "Short Titles"]
+    for top_k in (10, 4):
+        ce.pair_calls = ce.batch_calls = 0
+        batch = r.search_batch(qs, top_k=top_k)
+        assert ce.pair_calls == 1 and ce.batch_calls == 0
+        assert len(batch) == len(qs)
+        for q, got in zip(qs, batch):
+            exp = r.search(q, top_k=top_k)
+            assert [h.chunk.id for h in got] == [h.chunk.id for h in exp], q
+            assert [h.rank for h in got] == list(range(1, len(got) + 1))
+            assert [h.source for h in got] == [h.source for h in exp]
+            assert np.allclose([h.score for h in got], [h.score for h in exp], rtol=0, atol=2e-5)
+            for g, e in zip(got, exp):
+                assert g.score_breakdown.get("rerank_raw") == e.score_breakdown.get("rerank_raw")
+                assert g.score_breakdown.get("rerank_beta") == e.score_breakdown.get("rerank_beta")
+                if "rerank_norm" in e.score_breakdown:
+                    assert g.score_breakdown["rerank_norm"] == e.score_breakdown["rerank_norm"]
+        assert any(h.source == "rerank" for hits in batch for h in hits)
+    # a reranker without score_pairs (duck-typed, the reference's protocol) is fed query by query
+    class Plain:
+        def score_batch(self, query, docs):
+            return IdReranker().score_batch(query, docs)
+    monkeypatch.setattr(hr.RerankerFactory, "create", lambda self, top_k: Plain())
+    again = r.search_batch(qs, top_k=10)
+    first = r.search_batch(qs, top_k=10)
+    assert [[(h.chunk.id, h.score) for h in a] for a in again] == [[(h.chunk.id, h.score) for h in a] for a in first]
+
+
+def test_search_batch_runs_the_graph_stage_per_decision(ucc_index, monkeypatch):
+    """decisions[i].mode == GRAPH_AUGMENTED cuts query i's fused list to the seeds and appends the graph channel's
+    hits before rerank / dedup, exactly as search(decision=...) does (hybrid_retriever.py:312-322)."""
+    import types
+    from legal_rag_amd.retrieval import hybrid_retriever as hr
+    from legal_rag_amd.schemas import RetrievalHit
+    cfg, chunks = ucc_index
+    cfg2 = copy.deepcopy(cfg)
+    cfg2.retrieval.enable_graph = True
+    cfg2.retrieval.graph_seed_k = 4
+    ce = IdReranker()
+    monkeypatch.setattr(hr.RerankerFactory, "create", lambda self, top_k: ce)
+    r = hr.HybridRetriever(cfg2)
+    row = {c.id: i for i, c in enumerate(chunks)}
+
+    def graph_search(question, seeds, decision=None, top_k=10, **kw):  # neighbours = the next chunk of every seed
+        return [RetrievalHit(chunk=chunks[(row[h.chunk.id] + 1) % len(chunks)], score=0.9 - 0.1 * j, rank=j + 1,
+                             source="graph", score_breakdown={"channel": ["graph"], "graph_depth": 1})
+                for j, h in enumerate(seeds)]
+    r.graph = types.SimpleNamespace(search=graph_search)
+    dec = types.SimpleNamespace(mode="RoutingMode.GRAPH_AUGMENTED")
+    plain = types.SimpleNamespace(mode="RoutingMode.RAG")
+    qs = QUESTIONS[:4]
+    decisions = [dec, None, plain, dec]
+    batch = r.search_batch(qs, top_k=10, decisions=decisions)
+    graph_seen = 0
+    for q, d, got in zip(qs, decisions, batch):
+        exp = r.search(q, top_k=10, decision=d)
+        assert [h.chunk.id for h in got] == [h.chunk.id for h in exp], q
+        assert np.allclose([h.score for h in got], [h.score for h in exp], rtol=0, atol=2e-5)
+        assert [h.score_breakdown["channel"] for h in got] == [h.score_breakdown["channel"] for h in exp]
+        graph_seen += sum("graph" in h.score_breakdown["channel"] for h in got)
+        if d is dec:
+            assert len(got) <= 8  # 4 seeds + their 4 neighbours, before dedup
+    assert graph_seen > 0
+    with pytest.raises(ValueError, match="one entry per question"):
+        r.search_batch(qs, decisions=[dec])
+
+
 def test_search_native_stage_equals_per_channel_path(ucc_index, monkeypatch):
     """search() keeps the whole retrieval stage in HBM (one stream, one synchronise) when every
     channel is the package's own retriever; AMDR_SEARCH_NATIVE=0 pins the per-channel path of the
