@@ -20,6 +20,19 @@ import numpy as np
 from . import _native
 
 
+def shard_csr(term_ptr, post_doc, post_tf, doc_len, lo: int, hi: int):
+    """Doc-partitioned postings of the row block [lo, hi): every term keeps the postings of those documents only,
+    renumbered to local ids 0 .. hi-lo-1 (ascending per term, as the whole index); the term table — and with it the
+    caller's idf vector — keeps its full length, so term ids mean the same on every shard."""
+    lo, hi = int(lo), int(hi)
+    keep = (post_doc >= lo) & (post_doc < hi)
+    cnt = np.zeros(len(term_ptr), dtype=np.int64)
+    term_of = np.repeat(np.arange(len(term_ptr) - 1), np.diff(term_ptr))
+    np.add.at(cnt, term_of[keep] + 1, 1)
+    return (np.cumsum(cnt).astype(np.int64), (post_doc[keep] - lo).astype(np.int32), np.ascontiguousarray(post_tf[keep]),
+            np.ascontiguousarray(doc_len[lo:hi]))
+
+
 class BM25Okapi:
     def __init__(self, corpus: Optional[Sequence[Sequence[str]]] = None, tokenizer=None, k1: float = 1.5,
                  b: float = 0.75, epsilon: float = 0.25):
@@ -95,14 +108,20 @@ class BM25Okapi:
         idf = np.fromiter((self.idf[w] for w in vocab), dtype=np.float64, count=V)
         return term_ptr, post_doc, post_tf, idf, np.asarray(self.doc_len, dtype=np.int32)
 
-    def gpu(self, device: int = 0) -> "_native.BM25Index":
+    def gpu(self, device: int = 0, rows: Optional[tuple] = None) -> "_native.BM25Index":
+        """The postings in HBM.  rows = (lo, hi): only the documents of that block (doc-partitioned postings at
+        local ids 0 .. hi-lo-1) with the corpus-GLOBAL idf and avgdl — a row shard of a multi-GPU deployment
+        (retrieval/sharding.py); per-document scores are then bit-identical to the unsharded index's."""
+        key = (device, tuple(rows) if rows is not None else None)
         g = self.__dict__.get("_gpu")
-        if g is None or self.__dict__.get("_gpu_device") != device:
+        if g is None or self.__dict__.get("_gpu_device") != key:
             term_ptr, post_doc, post_tf, idf, doc_len = self.to_csr()
+            if rows is not None:
+                term_ptr, post_doc, post_tf, doc_len = shard_csr(term_ptr, post_doc, post_tf, doc_len, *rows)
             g = _native.BM25Index(term_ptr, post_doc, post_tf, idf, doc_len, float(self.avgdl), float(self.k1),
                                   float(self.b), device=device)
             self.__dict__["_gpu"] = g
-            self.__dict__["_gpu_device"] = device
+            self.__dict__["_gpu_device"] = key
         return g
 
     def term_ids(self, tokens: Sequence[str]) -> List[int]:
@@ -113,6 +132,14 @@ class BM25Okapi:
         """Same contract as rank_bm25's get_scores, computed by the HIP kernel."""
         return self.gpu(device).get_scores([self.term_ids(query)])[0]
 
-    def top_k(self, query: Sequence[str], k: int, device: int = 0):
-        s, i = self.gpu(device).search([self.term_ids(query)], k)
-        return s[0], i[0]
+    def top_k(self, query: Sequence[str], k: int, device: int = 0, shard=None):
+        """(scores, doc ids) of the k best documents.  shard = sharding.ShardSpec: this rank scores its row block,
+        the per-shard lists are all-gathered and merged; ids are global and identical on every rank."""
+        if shard is None:
+            s, i = self.gpu(device).search([self.term_ids(query)], k)
+            return s[0], i[0]
+        from .retrieval import sharding
+        lo, hi = shard.bounds(self.corpus_size)
+        s, i = self.gpu(device, rows=(lo, hi)).search([self.term_ids(query)], k)
+        (gs, gi), = sharding.exchange_topk_numpy([(s, i)], lo, device, group=shard.group)
+        return gs[0], gi[0]

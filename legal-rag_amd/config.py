@@ -76,6 +76,8 @@ class RetrievalConfig:
     device: int = 0                      # HIP device ordinal of this process
     encoder_backend: str = "auto"        # "auto" | "transformers" | "hashing" (deterministic stand-in)
     rerank_fp16: bool = False            # cross-encoder in half precision (the reference's CrossEncoder runs fp32)
+    shard: Optional[str] = None          # "rows": this process holds the row block of its torch.distributed rank in
+                                         # HBM and every search all-gathers the per-shard top-k (retrieval/sharding.py)
     zh_tokenizer: str = "jieba"          # "jieba" (raises if Han text meets no segmenter) | "char" (explicit
                                          # opt-in to the inexact one-character stand-in, text.py)
 

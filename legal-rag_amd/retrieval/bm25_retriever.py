@@ -42,6 +42,7 @@ class BM25Retriever:
         self._lock = threading.Lock()
         self.index_tokenizer: Optional[str] = None  # id recorded in bm25.pkl (None: reference-built)
         self._tls = threading.local()                 # per-thread: did the last query use the stand-in?
+        self.shard = None                             # sharding.ShardSpec in a row-sharded deployment
 
     def load(self) -> None:
         if not self.bm25_path.exists():
@@ -55,7 +56,10 @@ class BM25Retriever:
             if self._loaded and self._bm25_mtime == current_mtime:
                 return
             bm25, chunks = artifacts.read_bm25_pickle(self.bm25_path)
-            bm25.gpu(self.device_index)  # upload CSR postings now, not on the first query
+            from . import sharding
+            self.shard = sharding.active_shard(self.cfg.retrieval)  # row-sharded deployment: this rank's block only
+            # upload CSR postings now, not on the first query
+            bm25.gpu(self.device_index, rows=self.shard.bounds(bm25.corpus_size) if self.shard else None)
             self.bm25 = bm25
             self.chunks = chunks
             self.index_tokenizer = bm25.__dict__.get("_tokenizer_id")
@@ -64,6 +68,11 @@ class BM25Retriever:
                                "from a jieba-built index (zh_exact=False)", self.bm25_path)
             self._loaded = True
             self._bm25_mtime = current_mtime
+
+    def gpu_index(self):
+        """The _native.BM25Index this retriever scores with (this rank's row block in a sharded deployment)."""
+        self.load()
+        return self.bm25.gpu(self.device_index, rows=self.shard.bounds(self.bm25.corpus_size) if self.shard else None)
 
     def tokenize_query(self, query: str) -> List[str]:
         """bm25_retriever.py:73 — jieba.cut, not lower-cased.  Mode "char" when the index was built
@@ -98,12 +107,14 @@ class BM25Retriever:
         # the kernel ranks at most MAX_K per call; deeper requests take the dense score vector
         from .._native import MAX_K
         if k <= MAX_K:
-            scores, ids = self.bm25.top_k(tokens, min(k, MAX_K), device=self.device_index)
+            scores, ids = self.bm25.top_k(tokens, min(k, MAX_K), device=self.device_index, shard=self.shard)
             for s, i in zip(scores.tolist(), ids.tolist()):
                 if i < 0:
                     break
                 out.append((self.chunks[i], float(s)))
             return out
+        if self.shard is not None:
+            raise ValueError(f"sharded BM25 search: depth {k} exceeds the kernels' limit of {MAX_K}")
         scores = self.bm25.get_scores(tokens, device=self.device_index)
         idxs = sorted(range(n), key=lambda i: scores[i], reverse=True)[:k]
         return [(self.chunks[i], float(scores[i])) for i in idxs]

@@ -53,8 +53,8 @@ def _identity(rcfg) -> Tuple[str, str, str, str, str, int]:
 
 
 class ColBERTRetriever:
-    _instances_by_key: ClassVar[Dict[Tuple[str, str, str, str, str, int], "ColBERTRetriever"]] = {}
-    _searcher_cache: ClassVar[Dict[Tuple[str, str, str, str, int], "_native.MaxSimIndex"]] = {}
+    _instances_by_key: ClassVar[Dict[tuple, "ColBERTRetriever"]] = {}
+    _searcher_cache: ClassVar[Dict[tuple, Tuple["_native.MaxSimIndex", int]]] = {}  # (index, first pid of the shard)
     # from_config() constructs an instance (which fills the searcher cache) while holding the
     # registry lock: re-entrant on purpose
     _registry_lock: ClassVar[threading.RLock] = threading.RLock()
@@ -70,6 +70,7 @@ class ColBERTRetriever:
         self._collection: List[str] = []
         self._meta_mtime: Optional[float] = None
         self._searcher: Optional[_native.MaxSimIndex] = None
+        self.shard, self.row_offset = None, 0  # sharding.ShardSpec / first pid of this rank's block
         self._encoder = None
         if self.enabled:
             self._load_meta_and_collection()
@@ -77,7 +78,7 @@ class ColBERTRetriever:
 
     @classmethod
     def from_config(cls, cfg) -> "ColBERTRetriever":
-        key = _identity(cfg.retrieval)
+        key = _identity(cfg.retrieval) + (str(getattr(cfg.retrieval, "shard", None) or "none"),)
         with cls._registry_lock:
             if key not in cls._instances_by_key:
                 cls._instances_by_key[key] = cls(cfg)
@@ -104,13 +105,22 @@ class ColBERTRetriever:
         self._encoder = get_token_encoder(self.model_name, str(getattr(rcfg, "encoder_backend", "auto")),
                                           int(getattr(rcfg, "colbert_doc_maxlen", 220)),
                                           device=f"cuda:{self.device_index}")
-        key = (str(self.index_path), self.index_name, str(self.model_name), self.experiment, self.nranks)
+        from . import sharding
+        self.shard = sharding.active_shard(rcfg)
+        key = (str(self.index_path), self.index_name, str(self.model_name), self.experiment, self.nranks,
+               self.shard.key if self.shard else None)
         with type(self)._registry_lock:
             if key not in type(self)._searcher_cache:
                 tokens, doc_ptr = artifacts.read_token_store(
                     artifacts.colbert_index_dir(str(self.index_path), self.experiment, self.index_name))
-                type(self)._searcher_cache[key] = _native.MaxSimIndex(tokens, doc_ptr, device=self.device_index)
-            self._searcher = type(self)._searcher_cache[key]
+                lo = 0
+                if self.shard is not None:
+                    # row-sharded deployment: the token vectors of this rank's documents only (pid = lo + local id)
+                    lo, hi = self.shard.bounds(len(doc_ptr) - 1)
+                    tokens = np.ascontiguousarray(tokens[int(doc_ptr[lo]):int(doc_ptr[hi])])
+                    doc_ptr = np.ascontiguousarray(doc_ptr[lo:hi + 1] - doc_ptr[lo])
+                type(self)._searcher_cache[key] = (_native.MaxSimIndex(tokens, doc_ptr, device=self.device_index), lo)
+            self._searcher, self.row_offset = type(self)._searcher_cache[key]
 
     def search(self, query: str, top_k: int = 5) -> List[Tuple[LawChunk, float]]:
         if not self.enabled:
@@ -124,7 +134,14 @@ class ColBERTRetriever:
         depth = max(1, int(top_k))
         q_tokens = np.asarray(self._encoder.encode_query(question), dtype=np.float32)[None]
         try:
-            if depth <= _native.MAX_K:
+            if self.shard is not None:
+                if depth > _native.MAX_K:
+                    raise ValueError(f"sharded ColBERT search: depth {depth} exceeds the kernels' limit of {_native.MAX_K}")
+                from . import sharding
+                ls, lp = self._searcher.search(q_tokens, depth)
+                (scores, pids), = sharding.exchange_topk_numpy([(ls, lp)], self.row_offset, self.device_index,
+                                                               group=self.shard.group)
+            elif depth <= _native.MAX_K:
                 scores, pids = self._searcher.search(q_tokens, depth)
             else:  # beyond the kernels' depth: every document's MaxSim score, stable sort on the host
                 full = self._searcher.scores(q_tokens)[0]

@@ -56,7 +56,8 @@ class HybridEngine:
     def __init__(self, dense: Optional[_native.DenseIndex], bm25: Optional[_native.BM25Index],
                  maxsim: Optional[_native.MaxSimIndex] = None, *, device: int = 0,
                  dense_row2uid: Optional[torch.Tensor] = None, bm25_row2uid: Optional[torch.Tensor] = None,
-                 colbert_row2uid: Optional[torch.Tensor] = None):
+                 colbert_row2uid: Optional[torch.Tensor] = None, shard_offset: Optional[int] = None,
+                 shard_group=None):
         if not torch.cuda.is_available():
             raise RuntimeError("HybridEngine needs a GPU (no CPU fallback)")
         self.dense, self.bm25, self.maxsim = dense, bm25, maxsim
@@ -64,6 +65,11 @@ class HybridEngine:
         self.tdev = torch.device("cuda", self.device)
         self.maps = (dense_row2uid, bm25_row2uid, colbert_row2uid)
         self._bufs = {}
+        # Row-sharded corpus (retrieval/sharding.py): the three indexes hold this rank's row block (local ids
+        # 0 .. n_r - 1 = global ids shard_offset ..); search_batch then all-gathers the packed per-channel lists
+        # ONCE per batch, merges W*k -> k per channel (merge_parts_kernel) and fuses the GLOBAL lists — the
+        # result is identical on every rank.  None: one index holds everything, nothing is exchanged.
+        self.shard_offset, self.shard_group = shard_offset, shard_group
 
     def _buf(self, name, shape, dtype):
         key = (name, tuple(shape), dtype)
@@ -155,6 +161,11 @@ class HybridEngine:
         if self.maxsim is not None and q_tok is not None:
             c = self.colbert_topk(q_tok, k)
             nq = q_tok.shape[0]
+        if self.shard_offset is not None:
+            from . import sharding
+            chans = [x for x in (d, b, c) if x is not None]
+            merged = iter(sharding.exchange_topk(chans, int(self.shard_offset), group=self.shard_group))
+            d, b, c = (next(merged) if x is not None else None for x in (d, b, c))
         res = self.fuse(params, nq, d, b, c)
         if d is not None:
             res.dense_scores, res.dense_ids = d
@@ -179,6 +190,8 @@ class HybridEngine:
         channel on a forked branch of the captured graph — it does not depend on the dense channel — replays in
         45 us against 33 us for the plain chain: the fork / join nodes cost more than the 5-us kernel they hide.)
         """
+        if self.shard_offset is not None:
+            raise RuntimeError("capture: a sharded step contains a collective; it is not recorded into a hipGraph")
         nq = (q_emb.shape[0] if q_emb is not None else q_ptr.shape[0] - 1 if q_ptr is not None else q_tok.shape[0])
         self.reserve(int(nq), int(k), int(q_terms.numel()) if q_terms is not None else 0)
         side = torch.cuda.Stream(device=self.tdev)

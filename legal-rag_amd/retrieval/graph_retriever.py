@@ -86,10 +86,13 @@ class GraphRetriever:
         if index is not self._bound_index:  # store reloaded (mtime guard): rows may have moved
             self._bind_rows()
         if self._norms is None:
-            n, parts = int(index.ntotal), []
-            for lo in range(0, n, 65536):
-                parts.append(np.linalg.norm(index.reconstruct_n(lo, min(65536, n - lo)), axis=1))
-            self._norms = np.concatenate(parts) if parts else np.zeros(0, np.float32)
+            # a row-sharded index (vector_store.ShardedFlatIPIndex) holds rows [r0, r1) only: the norms of the other
+            # rows stay -inf here and come from their own rank in _semantic's all-reduce
+            r0, r1 = (index.row_offset, index.row_end) if hasattr(index, "spec") else (0, int(index.ntotal))
+            norms = np.full(int(index.ntotal), -np.inf, dtype=np.float32)
+            for lo in range(r0, r1, 65536):
+                norms[lo:min(lo + 65536, r1)] = np.linalg.norm(index.reconstruct_n(lo, min(65536, r1 - lo)), axis=1)
+            self._norms = norms
         return self._norms
 
     def _semantic(self, question: str, chunks: List[LawChunk], keys: List[str]) -> List[float]:
@@ -100,9 +103,24 @@ class GraphRetriever:
         sem = [0.0] * len(chunks)
         on_dev = np.nonzero(rows >= 0)[0]
         if on_dev.size:
-            dots = self.store.index.native.score_rows(qvec, rows[on_dev])[0]
-            for j, dot in zip(on_dev, dots):
-                sem[j] = float(np.float32(dot) / np.float32(np.float32(qn * norms[rows[j]]) + np.float32(1e-9)))
+            index = self.store.index
+            if hasattr(index, "spec"):
+                # row-sharded: every candidate row lives on exactly one rank — score the local ones, -inf for the
+                # rest, ONE all-reduce(max) of (dots, norms) over the ranks; identical on every rank afterwards
+                from . import sharding
+                g = rows[on_dev]
+                mine = (g >= index.row_offset) & (g < index.row_end)
+                both = np.full((2, g.size), -np.inf, dtype=np.float32)
+                if mine.any():
+                    both[0, mine] = index.native.score_rows(qvec, g[mine] - index.row_offset)[0]
+                    both[1, mine] = norms[g[mine]]
+                both = sharding.allreduce_max_numpy(both, index._device, group=index.spec.group)
+                dots, row_norms = both[0], both[1]
+            else:
+                dots = index.native.score_rows(qvec, rows[on_dev])[0]
+                row_norms = norms[rows[on_dev]]
+            for j, dot, rn in zip(on_dev, dots, row_norms):
+                sem[j] = float(np.float32(dot) / np.float32(np.float32(qn * rn) + np.float32(1e-9)))
         rest = [j for j in range(len(chunks)) if rows[j] < 0]
         if rest:
             vecs = self.store._embed([chunks[j].text for j in rest])

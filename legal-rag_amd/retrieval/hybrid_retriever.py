@@ -490,6 +490,23 @@ class HybridRetriever:
             return None
         return store, self.bm25, col
 
+    @staticmethod
+    def _make_engine(store, bm, col, dev: int):
+        """The device pipeline over the three retrievers' own indexes.  In a row-sharded deployment
+        (cfg.retrieval.shard = "rows") every index holds this rank's row block and the engine exchanges the
+        per-shard top-k once per batch (engine.HybridEngine, sharding.exchange_topk); the three blocks must be the
+        same rows, which contiguous blocks of one chunk list are."""
+        from .engine import HybridEngine
+        shard = getattr(store.index, "spec", None)
+        offset = None
+        if shard is not None:
+            offset = int(store.index.row_offset)
+            if getattr(bm, "shard", None) is None or (col is not None and (col.shard is None or col.row_offset != offset)):
+                raise RuntimeError("row-sharded search: the dense, BM25 and ColBERT channels must all be sharded "
+                                   "(load them under the same cfg.retrieval.shard and process group)")
+        return HybridEngine(store.index.native, bm.gpu_index(), col._searcher if col is not None else None,
+                            device=dev, shard_offset=offset, shard_group=shard.group if shard is not None else None)
+
     def _batch_native(self, questions: Sequence[str], eff: int, native, min_final: float, arrays: bool = False):
         """Embed / tokenise on the host, then dense + BM25 (+ MaxSim) top-k -> fuse -> min_final
         count for the whole batch on torch's current stream, one synchronise, results built once.
@@ -537,8 +554,7 @@ class HybridRetriever:
             engines = self.__dict__.get("_native_engine") or {}
             eng = engines.get(col is not None)
             if eng is None:
-                eng = HybridEngine(store.index.native, bm.bm25.gpu(dev), col._searcher if col is not None else None,
-                                   device=dev)
+                eng = self._make_engine(store, bm, col, dev)
                 engines[col is not None] = eng
                 self.__dict__["_native_engine"] = engines
             # BM25 query CSR in ONE host-to-device copy: q_ptr (i64) then q_terms (i32) in one byte buffer
@@ -556,7 +572,7 @@ class HybridRetriever:
                 # (hybrid_retriever.py:244-245, colbert_retriever.py:171-181); a dense / BM25 failure raises again here
                 eng = engines.get(False)
                 if eng is None:
-                    eng = engines[False] = HybridEngine(store.index.native, bm.bm25.gpu(dev), None, device=dev)
+                    eng = engines[False] = self._make_engine(store, bm, None, dev)
                 res = eng.search_batch(self._params(kn, min_final), eff, q_emb=q_emb, q_terms=q_terms_d, q_ptr=q_ptr_d)
             # ONE synchronise and ONE device-to-host copy (the four outputs share an allocation)
             ids, vals, mask, cnt = res.to_host()

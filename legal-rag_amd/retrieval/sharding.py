@@ -18,12 +18,50 @@ default has no CPU path.
 """
 from __future__ import annotations
 
-from typing import Callable, List, Optional, Sequence, Tuple
+from dataclasses import dataclass
+from typing import Any, Callable, List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
 from .. import _native
+
+
+@dataclass(frozen=True)
+class ShardSpec:
+    """This process's place in a row-sharded deployment (one process per GPU)."""
+    rank: int
+    world: int
+    group: Any = None
+
+    def bounds(self, n: int) -> Tuple[int, int]:
+        return shard_bounds(int(n), self.world)[self.rank]
+
+    @property
+    def key(self) -> Tuple[int, int]:
+        return (self.rank, self.world)
+
+
+def active_shard(rcfg) -> Optional[ShardSpec]:
+    """cfg.retrieval.shard = "rows": the retrievers of this process hold the row block of rank r of W in HBM and
+    every search exchanges the per-shard top-k (SPMD: every rank makes the same calls with the same arguments and
+    gets the same results).  None / "none": unsharded.  The process group is torch.distributed's default group
+    (backend nccl = RCCL on a GPU node) unless cfg.retrieval.shard_group names another; asking for shards without
+    an initialised process group is an error, never a silent fall-back to a whole-corpus index."""
+    mode = getattr(rcfg, "shard", None)
+    if mode in (None, "", "none", False):
+        return None
+    if str(mode) != "rows":
+        raise ValueError(f"cfg.retrieval.shard = {mode!r}: only 'rows' (contiguous row blocks) is implemented")
+    if not dist.is_available() or not dist.is_initialized():
+        raise RuntimeError("cfg.retrieval.shard = 'rows' needs an initialised torch.distributed process group "
+                           "(one process per GPU)")
+    group = getattr(rcfg, "shard_group", None)
+    world = dist.get_world_size(group)
+    if world == 1:
+        return None
+    return ShardSpec(rank=dist.get_rank(group), world=world, group=group)
 
 
 def shard_bounds(n: int, world: int) -> List[Tuple[int, int]]:
@@ -92,3 +130,23 @@ def exchange_topk(chans: Sequence[Tuple[torch.Tensor, torch.Tensor]], offset: in
     for (s, i), k in zip(unpack_channels(gathered, ks, dts), ks):
         out.append(merge_fn(s, i, k))
     return out
+
+
+def exchange_topk_numpy(chans: Sequence[Tuple[np.ndarray, np.ndarray]], offset: int, device: int, *, group=None):
+    """Host-array form for the per-channel API (VectorStore.search / BM25Retriever.search / ColBERTRetriever.search
+    in shard mode): local (scores, LOCAL ids) numpy arrays up to the card, exchange_topk there (the merge is the
+    HIP kernel on every backend), merged global lists back as numpy."""
+    tdev = torch.device("cuda", int(device))
+    up = [(torch.from_numpy(np.ascontiguousarray(s)).to(tdev), torch.from_numpy(np.ascontiguousarray(i)).to(tdev))
+          for s, i in chans]
+    with torch.cuda.device(tdev):
+        out = exchange_topk(up, offset, group=group)
+    return [(s.cpu().numpy(), i.cpu().numpy()) for s, i in out]
+
+
+def allreduce_max_numpy(a: np.ndarray, device: int, *, group=None) -> np.ndarray:
+    """Element-wise maximum over the ranks (graph rescoring: every candidate row lives on exactly one shard, the
+    others contribute -inf)."""
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(torch.device("cuda", int(device)))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return t.cpu().numpy()

@@ -71,8 +71,45 @@ class FlatIPIndex:
         return self._idx
 
 
+class ShardedFlatIPIndex(FlatIPIndex):
+    """This rank's row block [lo, hi) of the chunk matrix in HBM behind the same faiss-shaped facade: `search`
+    returns GLOBAL row ids of the global top-k — local scan, one all-gather of the per-shard lists, merge
+    (retrieval/sharding.py) — identical on every rank.  `ntotal` is the global row count; `native` is the local
+    index (rows lo .. hi-1 at local ids 0 .. hi-lo-1, `row_offset` = lo)."""
+
+    def __init__(self, X: np.ndarray, spec, device: int = 0):
+        self.spec = spec
+        self.n_global = int(X.shape[0])
+        self.row_offset, self.row_end = spec.bounds(self.n_global)
+        super().__init__(np.ascontiguousarray(X[self.row_offset:self.row_end]), device=device)
+        self._device = int(device)
+
+    @property
+    def ntotal(self) -> int:
+        return self.n_global
+
+    def search(self, q: np.ndarray, k: int):
+        from . import sharding
+        k = int(k)
+        if k > _native.MAX_K:
+            raise ValueError(f"sharded dense search: depth {k} exceeds the kernels' limit of {_native.MAX_K}")
+        s, i = self._idx.search(q, k)
+        (gs, gi), = sharding.exchange_topk_numpy([(s, i)], self.row_offset, self._device, group=self.spec.group)
+        return gs, gi
+
+    def add(self, x: np.ndarray) -> None:
+        raise RuntimeError("incremental add on a row-sharded index is not supported: rebuild and reload")
+
+    def reconstruct_n(self, i0: int, n: int) -> np.ndarray:
+        """rows by GLOBAL id; only this rank's block is resident"""
+        i0, n = int(i0), int(n)
+        if i0 < self.row_offset or i0 + n > self.row_end:
+            raise IndexError(f"rows [{i0}, {i0 + n}) are not in this rank's shard [{self.row_offset}, {self.row_end})")
+        return self._idx.read_rows(i0 - self.row_offset, n)
+
+
 class VectorStore:
-    _instances_by_key: ClassVar[Dict[Tuple[str, str, str, str], "VectorStore"]] = {}
+    _instances_by_key: ClassVar[Dict[Tuple[str, ...], "VectorStore"]] = {}
     _lock: ClassVar[threading.Lock] = threading.Lock()
 
     def __init__(self, cfg):
@@ -95,7 +132,7 @@ class VectorStore:
     def from_config(cls, cfg) -> "VectorStore":
         rcfg = cfg.retrieval
         key = (str(rcfg.embedding_model), str(rcfg.faiss_index_file), str(rcfg.faiss_meta_file),
-               f"cuda:{int(getattr(rcfg, 'device', 0))}")
+               f"cuda:{int(getattr(rcfg, 'device', 0))}", str(getattr(rcfg, "shard", None) or "none"))
         with cls._lock:
             inst = cls._instances_by_key.get(key)
             if inst is None:
@@ -117,7 +154,12 @@ class VectorStore:
                 return
             X, _metric = artifacts.read_faiss_index(self.index_path)
             chunks = artifacts.read_faiss_meta(self.meta_path)
-            self.index = FlatIPIndex(X, device=self.device_index)
+            from . import sharding
+            spec = sharding.active_shard(self.cfg.retrieval)
+            # row-sharded deployment: only this rank's row block goes to HBM; the chunk list (host) stays whole,
+            # global row id == position in it
+            self.index = (ShardedFlatIPIndex(X, spec, device=self.device_index) if spec is not None
+                          else FlatIPIndex(X, device=self.device_index))
             self.chunks = chunks
             self._index_mtime = index_mtime
             self._meta_mtime = meta_mtime

@@ -569,3 +569,38 @@ def test_depth_beyond_kernel_limit_is_handled_uniformly(ucc_index):
     big = [h for h in r.search_dense(q, 200)] * 2
     with pytest.raises(ValueError, match="exceed the fusion kernel"):
         r._fuse(dense_hits=big, bm25_hits=[], colbert_hits=[])
+
+
+def test_build_index_and_evaluate_retrieval_clis(tmp_path, capsys):
+    """BASELINE configs[0]'s recipe through the two CLIs (scripts/build_index.py:66-119 ->
+    scripts/evaluate_retrieval.py:65-125 in the reference): processed jsonl -> indexes in the reference's artifact
+    layout (versioned + activated) -> the evaluation summary table, on the GPU engine."""
+    import shutil
+    import sys
+    sys.path.insert(0, str(GOLDEN.parent.parent / "scripts"))
+    import build_index
+    import evaluate_retrieval
+    from legal_rag_amd.retrieval.vector_store import VectorStore
+    data = tmp_path / "data"
+    (data / "processed").mkdir(parents=True)
+    lines = (GOLDEN / "corpus" / "law_en.jsonl").read_text(encoding="utf-8").splitlines()[:150]
+    (data / "processed" / "law_en.jsonl").write_text("\n".join(lines) + "\n", encoding="utf-8")
+    build_index.main(["--data-dir", str(data), "--encoder-backend", "hashing", "--index-version", "v1", "--activate"])
+    root = data / "index" / "en"
+    assert (root / "ACTIVE").read_text() == "v1"
+    for rel in ("faiss/faiss.index", "faiss/faiss_meta.jsonl", "bm25.pkl", "colbert/colbert_meta.jsonl"):
+        assert (root / "versions" / "v1" / rel).exists(), rel
+    out = tmp_path / "rows.jsonl"
+    VectorStore._instances_by_key.clear()
+    evaluate_retrieval.main(["--data-dir", str(data), "--lang", "en", "--synthetic", "--limit", "20",
+                             "--encoder-backend", "hashing", "--no-rerank", "--output", str(out)])
+    txt = capsys.readouterr().out
+    assert "Evaluation Summary over 20 queries" in txt
+    rows = [__import__("json").loads(l) for l in out.read_text().splitlines()]
+    systems = {r["system"] for r in rows}
+    assert systems == {"bm25", "dense", "colbert", "fused", "fused+graph", "hybrid"} and len(rows) == 6 * 20
+    mean = lambda name, k: float(np.mean([r[k] for r in rows if r["system"] == name]))  # noqa: E731
+    assert mean("fused", "R@10") >= max(mean("bm25", "R@10"), 0.5)  # fusion is not worse than the weakest channel
+    assert mean("hybrid", "R@10") == mean("fused", "R@10") or mean("hybrid", "R@10") > 0.5
+    assert all(0.0 <= r[k] <= 1.0 for r in rows for k in ("R@5", "R@10", "MRR@10", "nDCG@10", "Hit@3", "Hit@10"))
+    shutil.rmtree(data)

@@ -215,6 +215,49 @@ def test_dense_two_level_topk_equals_full_score_matrix(nat, monkeypatch):
 
 
 
+def test_dense_two_level_and_full_form_with_nan_scores(nat, monkeypatch):
+    """NaN scores (a NaN in a chunk row) sort LAST in the full form (they still fill the tail of a top-k that has
+    fewer than k real scores); the two-level form never returns them — a maximum drops NaN, so an all-NaN tile is no
+    candidate — and pads with (id -1, -FLT_MAX), the convention for "fewer than k results".  The two forms agree on
+    every real score, and differ only there; neither reads an unwritten list entry."""
+    rng = np.random.default_rng(17)
+    n, d, nq, k = 64 * 12 + 11, 64, 9, 10
+    X, Q = unit_rows(rng, n, d), unit_rows(rng, nq, d)
+    real = [3, 40, 100, 333, 500, 700]            # fewer than k rows keep a real score
+    Xn = np.full_like(X, np.nan)
+    Xn[real] = X[real]
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("AMDR_DENSE_TWO_LEVEL", flag)
+        idx = nat.DenseIndex(Xn)
+        out[flag] = idx.search(Q, k)
+        idx.close()
+    exp = (X[real].astype(np.float64) @ Q.astype(np.float64).T).T
+    for b in range(nq):
+        order = [real[j] for j in np.argsort(-exp[b], kind="stable")]
+        for flag in ("1", "0"):
+            s, i = out[flag]
+            assert i[b, :len(real)].tolist() == order, (flag, b)
+            assert np.allclose(s[b, :len(real)], np.sort(exp[b])[::-1], atol=TOL)
+        s2, i2 = out["1"]
+        assert (i2[b, len(real):] == -1).all() and (s2[b, len(real):] == -np.finfo(np.float32).max).all()
+        s0, i0 = out["0"]
+        tail = i0[b, len(real):]
+        assert np.isnan(s0[b, len(real):]).all() and (tail >= 0).all() and (tail < n).all()
+        assert tail.tolist() == sorted(tail.tolist()) and not set(tail.tolist()) & set(real)
+    # with at least k real scores the NaN rows change nothing: both forms, same bits
+    Xm = X.copy()
+    Xm[::7] = np.nan
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("AMDR_DENSE_TWO_LEVEL", flag)
+        idx = nat.DenseIndex(Xm)
+        res[flag] = idx.search(Q, k)
+        idx.close()
+    assert np.array_equal(res["1"][1], res["0"][1]) and np.array_equal(res["1"][0], res["0"][0])
+    assert not np.isnan(res["1"][0]).any() and not (res["1"][1] % 7 == 0).any()
+
+
 def test_dense_golden_fixture(nat):
     """Seeded fixture of SURVEY.md §8c(3): X[4096,768], Q[16,768], rng(0)."""
     g = np.load(str(__import__("conftest").GOLDEN / "dense_flatip_golden.npz"))
@@ -664,6 +707,39 @@ def test_fuse_filter_rerank_pipeline_vs_reference_vectors(nat, case):
         rer = nat.rerank_blend(count, ids, vals, mask, raw, float(full["rerank_beta"]))[0]
     got = _hits_from_native(nat, ids[0], vals[0], mask[0], count[0], full, rer=rer, beta=float(full["rerank_beta"]))
     assert_hits_equal_mod_ties(got[:top_k], case["expected"])
+
+
+def test_fuse_and_rerank_reproduce_the_notebook_known_answers(nat):
+    """The only fusion numbers the reference itself holds (notebooks/03_Retrieval_Performance_Evaluation.ipynb,
+    query "认购书或者订购书等是否属于预约合同？"): article 495 is rank 1 in all three channels (:1068 BM25 37.36,
+    :1188 dense 0.65, ColBERT 22.08), its fused score prints 1.18 (:1257) and its score after the rerank blend 1.11
+    (:1529).  With the defaults (config.py:92-93,100,121-122: weights 0.6 / 0.4 / 0.35, rrf_alpha 0.5,
+    rerank_beta 0.35) the formula gives alpha*1 + (1-alpha)*(0.6+0.4+0.35) = 1.175 and
+    0.65*1.175 + 0.35*1 = 1.11375 — through amdr_fuse and amdr_rerank_blend, to the bit.  The channel lists are the
+    notebook's printed top-5 (article ids and 2-digit scores); the hits it prints below 495 depend on ranks 6-10,
+    which it does not show."""
+    dense = [(495, 0.65), (491, 0.53), (471, 0.5299), (493, 0.51), (483, 0.5099)]
+    bm25 = [(495, 37.36), (1134, 8.09), (501, 7.53), (250, 7.47), (254, 7.03)]
+    colbert = [(495, 22.08), (502, 19.97), (493, 19.92), (888, 19.88), (984, 19.84)]
+
+    def arr(pairs, dt):
+        return (np.array([[i for i, _ in pairs]], dtype=np.int64), np.array([[s for _, s in pairs]], dtype=dt))
+    params = nat.make_fuse_params(method="rrf_norm_blend", rrf_k=60, alpha=0.5, w_dense=0.6, w_bm25=0.4, w_colbert=0.35,
+                                  min_final_score=0.2)
+    ids, vals, mask, count = nat.fuse(params, 1, arr(dense, np.float32), arr(bm25, np.float64), arr(colbert, np.float32))
+    assert ids[0, 0] == 495 and mask[0, 0] == 7
+    assert vals[0, 0, nat.FV["rrf_norm"]] == 1.0 and vals[0, 0, nat.FV["weighted_sum"]] == 0.6 + 0.4 + 0.35
+    assert vals[0, 0, nat.FV["score"]] == 0.5 * 1.0 + (1 - 0.5) * (0.6 + 0.4 + 0.35) == 1.175
+    assert f"{vals[0, 0, 0]:.2f}" == "1.18"  # what the notebook prints
+    # the hits the notebook lists under it all sit in dense AND colbert or dense only: 493 is in both here
+    by_id = {int(i): r for r, i in enumerate(ids[0, :count[0]])}
+    assert mask[0, by_id[493]] == 0b101
+    n = int(count[0])
+    raw = np.array([[0.99] + [0.5 - 0.01 * j for j in range(n - 1)]], dtype=np.float64)  # CE prefers 495 as well
+    rr = nat.rerank_blend(count, ids, vals, mask, raw, 0.35)
+    assert ids[0, 0] == 495 and rr[0, 0, 1] == 1.0
+    assert vals[0, 0, 0] == (1 - 0.35) * 1.175 + 0.35 * 1.0
+    assert abs(vals[0, 0, 0] - 1.11375) < 1e-15 and f"{vals[0, 0, 0]:.2f}" == "1.11"
 
 
 def test_fuse_batched_equals_single(nat):

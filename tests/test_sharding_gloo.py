@@ -99,3 +99,77 @@ def test_pack_unpack_roundtrip_is_bit_exact():
 def test_native_merge_refuses_cpu_tensors():
     with pytest.raises(RuntimeError):
         sharding.native_merge(torch.zeros((2, 1, 3)), torch.zeros((2, 1, 3), dtype=torch.int64), 3)
+
+
+def test_shard_mode_without_a_process_group_fails_loudly():
+    """cfg.retrieval.shard = "rows" outside torch.distributed is an error, never a silent whole-corpus index."""
+    from legal_rag_amd.config import AppConfig
+    cfg = AppConfig()
+    assert sharding.active_shard(cfg.retrieval) is None  # default: unsharded
+    cfg.retrieval.shard = "rows"
+    with pytest.raises(RuntimeError, match="process group"):
+        sharding.active_shard(cfg.retrieval)
+    cfg.retrieval.shard = "columns"
+    with pytest.raises(ValueError, match="only 'rows'"):
+        sharding.active_shard(cfg.retrieval)
+
+
+def test_shard_csr_partitions_the_postings():
+    """The shards' posting lists are a partition of the whole index's: same (term, doc, tf) triples, local ids
+    ascending per term, the term table of full length on every shard."""
+    from legal_rag_amd.bm25_model import BM25Okapi, shard_csr
+    rng = np.random.default_rng(3)
+    docs = [[f"w{j}" for j in rng.integers(0, 50, size=int(rng.integers(1, 30)))] for _ in range(97)]
+    tp, pd, pt, idf, dl = BM25Okapi(docs).to_csr()
+    whole = sorted((t, int(pd[j]), int(pt[j])) for t in range(len(tp) - 1) for j in range(tp[t], tp[t + 1]))
+    for world in (2, 3, 8):
+        got = []
+        for lo, hi in sharding.shard_bounds(len(docs), world):
+            stp, spd, spt, sdl = shard_csr(tp, pd, pt, dl, lo, hi)
+            assert len(stp) == len(tp) and stp[0] == 0 and stp[-1] == len(spd) == len(spt)
+            assert sdl.tolist() == dl[lo:hi].tolist()
+            for t in range(len(stp) - 1):
+                seg = spd[stp[t]:stp[t + 1]]
+                assert (np.diff(seg) > 0).all() and ((seg >= 0) & (seg < hi - lo)).all()
+                got += [(t, int(d) + lo, int(f)) for d, f in zip(seg, spt[stp[t]:stp[t + 1]])]
+        assert sorted(got) == whole
+
+
+def _spec_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from legal_rag_amd.config import AppConfig
+    cfg = AppConfig()
+    cfg.retrieval.shard = "rows"
+    spec = sharding.active_shard(cfg.retrieval)
+    assert spec is not None and spec.rank == rank and spec.world == world and spec.key == (rank, world)
+    assert spec.bounds(591) == sharding.shard_bounds(591, world)[rank]
+    # three channels (f32, f64, f32) in ONE collective, as the sharded engine packs them
+    rng = np.random.default_rng(11 + rank)
+    nq, k = 5, 4
+    chans = [(torch.from_numpy(np.sort(rng.standard_normal((nq, k)).astype(dt))[:, ::-1].copy()),
+              torch.from_numpy(rng.integers(0, 50, size=(nq, k)))) for dt in (np.float32, np.float64, np.float32)]
+    calls = []
+    real = dist.all_gather_into_tensor
+
+    def counting(*a, **kw):
+        calls.append(1)
+        return real(*a, **kw)
+    dist.all_gather_into_tensor = counting
+    out = sharding.exchange_topk(chans, 100 * rank, merge_fn=oracle_merge)
+    dist.all_gather_into_tensor = real
+    assert len(calls) == 1 and len(out) == 3
+    assert [o[0].dtype for o in out] == [torch.float32, torch.float64, torch.float32]
+    torch.save([(s, i) for s, i in out], os.path.join(out_dir, f"x_{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_active_shard_and_three_channel_exchange_world2_gloo(tmp_path):
+    mp.spawn(_spec_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "x_0.pt"), torch.load(tmp_path / "x_1.pt")
+    for (sa, ia), (sb, ib) in zip(a, b):
+        assert torch.equal(sa, sb) and torch.equal(ia, ib)
+        assert (ia >= 0).all() and (ia.max() >= 100)  # global ids: rank 1's carry its offset
+        assert (sa[:, :-1] >= sa[:, 1:]).all()
