@@ -307,12 +307,22 @@ def event_ms(torch, fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
-def maxsim_roofline(ms, tokens, nq, q_len=32, dim=128, note=""):
+F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16 / bf16 matrix peak
+
+
+def maxsim_roofline(ms, tokens, nq, q_len=32, dim=128, note="", plan=""):
+    """MaxSim channel against the matrix peak of the form that ran (MaxSimIndex.plan_info).  Algorithmic flops =
+    2 * q_len * dim * tokens per query.  The split-fp16 form takes every product as three exact fp16 partial products
+    (hi*hi, hi*lo, lo*hi): `achieved` counts those executed flops (3 x algorithmic) against the fp16 peak; the
+    fp32-input form executes the algorithmic flops against the fp32 matrix peak."""
     flops = 2.0 * q_len * dim * tokens * nq
-    ach = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "maxsim_scores_blocked_kernel + rowscores_topk_kernel (v_mfma_f32_16x16x4_f32)",
-            "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
-            "traffic": None, "launch_ms": ms, "algorithmic_flops": flops,
+    half = "split-fp16" in plan
+    executed = 3.0 * flops if half else flops
+    peak = F16_MFMA_PEAK_TFLOPS if half else F32_MFMA_PEAK_TFLOPS
+    ach = executed / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": plan or "maxsim", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+            "frac": ach / peak, "traffic": None, "launch_ms": ms, "algorithmic_flops": flops, "executed_flops": executed,
+            "algorithmic_TFLOPs": flops / (ms * 1e-3) / 1e12,
             "algorithmic_bytes": float(tokens) * dim * 4 + float(nq) * q_len * dim * 4, "note": note}
 
 
@@ -339,7 +349,8 @@ def run_ucc_colbert(torch, local, params, K, steps):
            "recall_at_10": hybrid_recall(ids, cnt, W["chunks"], W["queries"], K),
            "agreement_at_10_vs_oracle": agreement(ids, cnt, oracle_pipeline(W, sample, K), sample, K),
            "colbert_doc_tokens": tokens, "maxsim_gflop_per_query": 2.0 * 32 * 128 * tokens / 1e9,
-           "roofline": maxsim_roofline(ms, tokens, R.nq, note="MaxSim channel (scores + top-k launches), HIP events")}
+           "roofline": maxsim_roofline(ms, tokens, R.nq, note="MaxSim channel (scores + top-k launches), HIP events",
+                                       plan=R.maxsim.plan_info(R.nq))}
     R.close()
     return out
 
@@ -477,7 +488,7 @@ def run_full_hybrid_rerank(torch, local, K, steps, dist=None, world=1, rank=0):
             dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
             info["identical_on_every_rank"] = bool(torch.equal(lo_, hi_))
         per_lang[lang] = info
-    roof = maxsim_roofline(ms_total, tok_q / nq, nq,
+    roof = maxsim_roofline(ms_total, tok_q / nq, nq, plan=next(iter(langs.values()))[1].maxsim.plan_info(nq),
                            note="MaxSim launches of both languages on this rank's shard (dominant kernel of this step), "
                                 "HIP events")
     out = {"workload": "Civil-Code-zh (1 260 chunks) + UCC-en (591 chunks), language-routed, dense+BM25+ColBERT -> "

@@ -125,10 +125,16 @@ int amdr_bm25_destroy(amdr_bm25_t* h);
 /* ---- ColBERT channel: exhaustive late-interaction MaxSim ---------------
  * Replaces `Searcher.search(query, k)` (legalrag/retrieval/colbert_retriever.py:152).
  * D: fp32 token embeddings [total_tokens, 128], doc_ptr[n_docs+1] (every doc
- * has >= 1 token); Q: [nq, 32, 128].  score = sum_i max_j <q_i, d_j>. */
+ * has >= 1 token); Q: [nq, 32, 128].  score = sum_i max_j <q_i, d_j>.
+ * Arithmetic: every operand is split exactly into fp16 hi + lo / 2048 (22 significant bits) and a product is
+ * hi*hi + (hi*lo + lo*hi) / 2048 on the fp16 matrix instructions with fp32 accumulation — scores within ~3e-6 of
+ * the fp64 definition on unit-norm tokens (north_star's bar: 1e-4), scale-free for any finite input; a store
+ * holding a NaN / infinity, or AMDR_MAXSIM_F16X3=0, takes the exact fp32-input matrix form (csrc/maxsim.hip). */
 int amdr_maxsim_create(const float* D_host, const int64_t* doc_ptr, int64_t n_docs, int32_t dim,
                        int32_t device, amdr_maxsim_t** out);
 int amdr_maxsim_ndocs(const amdr_maxsim_t* h, int64_t* n);
+/* which kernels a search of nq queries would launch and in which arithmetic form (NUL-terminated; no device work) */
+int amdr_maxsim_plan_info(const amdr_maxsim_t* h, int32_t nq, char* buf, int32_t buf_len);
 int amdr_maxsim_reserve(amdr_maxsim_t* h, int32_t nq_max, int32_t k_max);
 int amdr_maxsim_search(amdr_maxsim_t* h, const float* Q_host, int32_t nq, int32_t q_len, int32_t k,
                        float* scores_host, int64_t* ids_host);

@@ -33,7 +33,7 @@ EXPORTS = (
     "amdr_dense_plan_info", "amdr_dense_workspace_plan", "amdr_dense_profile_begin", "amdr_dense_profile_end", "amdr_dense_destroy",
     "amdr_bm25_create", "amdr_bm25_ndocs", "amdr_bm25_reserve", "amdr_bm25_search", "amdr_bm25_search_device",
     "amdr_bm25_scores", "amdr_bm25_destroy",
-    "amdr_maxsim_create", "amdr_maxsim_ndocs", "amdr_maxsim_reserve", "amdr_maxsim_search",
+    "amdr_maxsim_create", "amdr_maxsim_ndocs", "amdr_maxsim_plan_info", "amdr_maxsim_reserve", "amdr_maxsim_search",
     "amdr_maxsim_search_device", "amdr_maxsim_scores", "amdr_maxsim_destroy",
     "amdr_fuse", "amdr_fuse_device", "amdr_rerank_blend", "amdr_rerank_blend_device",
     "amdr_merge_topk_f32_device", "amdr_merge_topk_f64_device",
@@ -53,7 +53,7 @@ SIGNATURES = {
     "amdr_bm25_create": "PPPPPlldddiP", "amdr_bm25_ndocs": "PP", "amdr_bm25_reserve": "Piil",
     "amdr_bm25_search": "PPPiiPP", "amdr_bm25_search_device": "PPPiiPPP", "amdr_bm25_scores": "PPPiP",
     "amdr_bm25_destroy": "P",
-    "amdr_maxsim_create": "PPliiP", "amdr_maxsim_ndocs": "PP", "amdr_maxsim_reserve": "Pii",
+    "amdr_maxsim_create": "PPliiP", "amdr_maxsim_ndocs": "PP", "amdr_maxsim_plan_info": "PiPi", "amdr_maxsim_reserve": "Pii",
     "amdr_maxsim_search": "PPiiiPP", "amdr_maxsim_search_device": "PPiiiPPP", "amdr_maxsim_scores": "PPiiP",
     "amdr_maxsim_destroy": "P",
     "amdr_fuse": "Pi" + "PPi" * 3 + "PPPP", "amdr_fuse_device": "Pi" + "PPiP" * 3 + "PPPP" + "iP",
@@ -344,6 +344,12 @@ class MaxSimIndex:
         _check(load().amdr_maxsim_create(_p(D, C.c_float), _p(doc_ptr, C.c_int64), C.c_int64(self.n_docs),
                                          C.c_int32(self.dim), C.c_int32(device), C.byref(self._h)),
                "amdr_maxsim_create")
+
+    def plan_info(self, nq: int) -> str:
+        """Kernels and arithmetic form a search of nq queries launches (no device work)."""
+        buf = C.create_string_buffer(512)
+        _check(load().amdr_maxsim_plan_info(self._h, C.c_int32(nq), buf, C.c_int32(512)), "amdr_maxsim_plan_info")
+        return buf.value.decode()
 
     def reserve(self, nq_max: int, k_max: int) -> None:
         _check(load().amdr_maxsim_reserve(self._h, C.c_int32(nq_max), C.c_int32(k_max)), "amdr_maxsim_reserve")

@@ -18,11 +18,16 @@
 #include "topk.hpp"
 
 #include <cfloat>
+#include <cmath>
+#include <cstring>
 #include <mutex>
 #include <new>
 
 namespace amdr {
 
+
+#define AMDR_MS_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define AMDR_MS_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 constexpr int kMsWaves = 4;
 constexpr int kDim = AMDR_MAXSIM_DIM;  // 128
@@ -80,6 +85,115 @@ __device__ __forceinline__ void ms_tile(const ms4f (&a)[2][8], const ms4f (&q)[2
     }
 }
 
+// ---- split-fp16 form ("f16x3") -------------------------------------------------------------------------------
+// The same tile on the fp16 matrix instructions (v_mfma_f32_32x32x16_f16: 16x the rate of the fp32-input form).
+// fp16 alone (11 significant bits) would miss the 1e-4 bar, so every operand x (scaled by a power of two into
+// [-1, 1], see below) is split EXACTLY into
+//     x = hi + lo / 2048,   hi = fp16(x),   lo = fp16((x - hi) * 2048)
+// (x - hi is exact in fp32; lo keeps its next 11 bits: 22 significant bits in all), and a product is taken as
+//     a*b ~= a_hi*b_hi + (a_hi*b_lo + a_lo*b_hi) / 2048
+// — three fp16 MFMAs instead of the fp32-input sequence, every fp16 x fp16 product exact in the fp32 accumulator;
+// only the a_lo*b_lo term (2^-22 of the product) is dropped.  The cross terms run in their own accumulator and are
+// folded in with one fma per score.  Measured on the UCC-en / Civil-Code-zh token stores against the fp64 oracle:
+// max |score error| 2.0e-6 / 2.5e-6 on scores of ~20 (the fp32-input form: 3.7e-6 / 2.8e-6 — its 128-term fp32
+// chains round more often), ranks identical (tests/test_kernels_gpu.py).  Document tokens are split ONCE at index
+// creation into a [hi 128 x fp16 | lo 128 x fp16] image of the same 512 bytes per token as the fp32 row (same LDS
+// tile, same swizzle); a query is split by its wave at kernel start.  Power-of-two scales (the store's: from its
+// largest |component| at creation; a query's: from its own) keep hi / lo inside fp16's range for any finite input
+// and are undone exactly on the per-token maxima.  AMDR_MAXSIM_F16X3=0 pins the fp32-input form.
+//
+// Shape: one 32x32x16 accumulator (16 registers) has the query token on the lane (l & 31) and 16 document tokens in
+// the lane's registers: rows (reg & 3) + 8 (reg >> 2) + 4 (l >> 5).
+//   A (32 doc tokens x 16):   lane (r = l & 31, h = l >> 5) holds row r, k = 16 s + 8 h .. + 7 = 16-B chunk 2 s + h
+//   B (16 x 32 query tokens): the same of query-token row r.
+// An MFMA holds its SIMD's vector issue for 8 cycles whatever its shape (MI355X_MICROARCH.md): 8 of 16 for a
+// 16x16x32, 8 of 32 for a 32x32x16 — the first version of this form ran 48 16x16x32 MFMAs per tile and was bound by
+// the issue port (PMC: ~100 vector + 50 scalar instructions per wave and tile beside them, matrix pipe 51 % busy;
+// staggering the two waves of a SIMD by half a step gained 10 %); 24 of the wide shape leave 3x the issue slots:
+// 2.40 -> 2.23 ms per 1 168 UCC-en queries (fp32-input form: 6.78 ms).  What bounds it now is POWER: under this kernel
+// the chip holds 1.70 GHz (GRBM_GUI_ACTIVE; 2.11 GHz under the fp32-input dense kernel), the matrix pipe is busy 67 %
+// of those cycles (77 % with DMA and barriers taken out in a timing-only build, which runs 2.10 ms); at the held
+// clock the MFMAs alone need 1.63 ms.
+typedef _Float16 ms8h __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr float kMsLoScale = 2048.f, kMsLoInv = 1.f / 2048.f;
+
+__device__ __forceinline__ void ms_split(const float (&x)[8], float s, ms8h& hi, ms8h& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = x[j] * s;
+    const _Float16 h = (_Float16)v;
+    hi[j] = h;
+    lo[j] = (_Float16)((v - (float)h) * kMsLoScale);
+  }
+}
+
+// A query's fragments, split (lane (r, h): token row r, chunks 2 s + h); rows past q_len are zero; the wave's
+// power-of-two scale comes back in `unscale` (1 / scale, exact).
+__device__ __forceinline__ void ms_load_query_h(const float* __restrict__ Qq, int q_len, bool live, int r, int h,
+                                                ms8h (&qh)[8], ms8h (&ql)[8], float& unscale) {
+  float x[8][8];
+  float m = 0.f;
+  const bool out = !live || r >= q_len;
+  const float* p = Qq + (size_t)(r < q_len ? r : q_len - 1) * kDim + 8 * h;
+#pragma unroll
+  for (int st = 0; st < 8; ++st) {
+    ms4f v0 = ms4f{0.f, 0.f, 0.f, 0.f}, v1 = v0;
+    if (live) {
+      v0 = *reinterpret_cast<const ms4f*>(p + 16 * st);
+      v1 = *reinterpret_cast<const ms4f*>(p + 16 * st + 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      x[st][j] = out ? 0.f : v0[j];
+      x[st][4 + j] = out ? 0.f : v1[j];
+      m = fmaxf(m, fmaxf(fabsf(x[st][j]), fabsf(x[st][4 + j])));
+    }
+  }
+#pragma unroll
+  for (int sft = 1; sft < 64; sft <<= 1) m = fmaxf(m, __shfl_xor(m, sft));
+  int e = 0;
+  if (m > 0.f && m <= FLT_MAX) (void)frexpf(m, &e);  // m = f * 2^e, f in [0.5, 1)
+  const float sc = ldexpf(1.f, -e);
+  unscale = ldexpf(1.f, e);
+#pragma unroll
+  for (int st = 0; st < 8; ++st) ms_split(x[st], sc, qh[st], ql[st]);
+}
+
+// One 32 x 32 tile: 24 MFMAs, then the lane's maximum over its 16 document tokens (rows >= remain are no tokens of
+// the document: masked on the last tile of a document only — a real, wave-uniform branch: if-converted, the 32
+// compare / select pairs ran on every tile).  Both kernels of this form call it: identical bits.
+__device__ __forceinline__ void ms_tile_h(const ms8h (&ah)[8], const ms8h (&al)[8], const ms8h (&qh)[8],
+                                          const ms8h (&ql)[8], int h, int remain, float& best) {
+  f32x16 am, ac;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) am[j] = ac[j] = 0.f;
+#pragma unroll
+  for (int st = 0; st < 8; ++st) {
+    am = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st], qh[st], am, 0, 0, 0);
+    ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st], ql[st], ac, 0, 0, 0);
+    ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[st], qh[st], ac, 0, 0, 0);
+  }
+  float v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) v[j] = __builtin_fmaf(ac[j], kMsLoInv, am[j]);
+  if (remain < 32) {
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (((j & 3) + 8 * (j >> 2) + 4 * h) >= remain) v[j] = -FLT_MAX;
+  }
+#pragma unroll
+  for (int j = 0; j < 16; j += 2) best = fmaxf(best, fmaxf(v[j], v[j + 1]));
+}
+
+// Document score from the per-lane maxima: max over the two row halves, sum over the q_len query tokens (lanes
+// 0..31 of h = 0), scales undone (powers of two: exact).
+__device__ __forceinline__ float ms_finish_h(float best, int r, int h, int q_len, float unscale) {
+  const float b = fmaxf(best, __uint_as_float(lane_xor<32>(__float_as_uint(best))));
+  return ms_wave_sum((h == 0 && r < q_len) ? b * unscale : 0.f);
+}
+
 // Document score from the per-lane maxima: max over the four kq groups, then sum over the
 // q_len query tokens (lane group kq = 0 holds token 16 bj + i16 in best[bj]).
 __device__ __forceinline__ float ms_finish(const float (&best)[2], int i16, int kq, int q_len) {
@@ -92,6 +206,35 @@ __device__ __forceinline__ float ms_finish(const float (&best)[2], int i16, int 
     if (kq == 0 && 16 * bj + i16 < q_len) contrib += b;
   }
   return ms_wave_sum(contrib);
+}
+
+// fp32 token rows -> the [hi | lo] image (one thread per 8 components), scaled by the store's power of two
+__global__ __launch_bounds__(256) void ms_split_store_kernel(const float* __restrict__ D, long n_tokens, float scale,
+                                                             unsigned char* __restrict__ img) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;  // (token, group of 8 components)
+  if (i >= n_tokens * 16) return;
+  const long tok = i >> 4;
+  const int g = (int)(i & 15);
+  float x[8];
+  const ms4f v0 = *reinterpret_cast<const ms4f*>(D + tok * kDim + 8 * g);
+  const ms4f v1 = *reinterpret_cast<const ms4f*>(D + tok * kDim + 8 * g + 4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) x[j] = v0[j], x[4 + j] = v1[j];
+  ms8h hi, lo;
+  ms_split(x, scale, hi, lo);
+  *reinterpret_cast<ms8h*>(img + tok * 512 + 16 * g) = hi;
+  *reinterpret_cast<ms8h*>(img + tok * 512 + 256 + 16 * g) = lo;
+}
+
+// largest |component| of the store as float bits (non-negative floats order like unsigned integers; NaN sorts
+// above infinity, so a non-finite store is visible in the result)
+__global__ __launch_bounds__(256) void ms_absmax_kernel(const float* __restrict__ D, long n, unsigned int* __restrict__ out) {
+  unsigned int m = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    m = max(m, __float_as_uint(D[i]) & 0x7fffffffu);
+#pragma unroll
+  for (int sft = 1; sft < 64; sft <<= 1) m = max(m, (unsigned int)__shfl_xor((int)m, sft));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 
 // The lane's fragment of a 32-row x 128-float operand in global memory: rows row0 + 16 b + i16
@@ -112,7 +255,7 @@ __device__ __forceinline__ void ms_load_frag(const float* __restrict__ base, lon
   }
 }
 
-// grid: (x = ceil(n_docs / 4), y = queries); one wave per document (1-7 queries: latency form).
+// grid: (x = ceil(n_docs / 4), y = queries); one wave per document (1-7 queries: latency form), fp32-input form.
 __global__ __launch_bounds__(256) void maxsim_scores_kernel(const float* __restrict__ D,
                                                              const long long* __restrict__ doc_ptr, long n_docs,
                                                              const float* __restrict__ Q, int q_len,
@@ -138,6 +281,39 @@ __global__ __launch_bounds__(256) void maxsim_scores_kernel(const float* __restr
       ms_tile<2>(af, qf, kq, len - tok0, best);
   }
   const float total = ms_finish(best, i16, kq, q_len);
+  if (lane == 0) scores[(size_t)qi * n_docs + doc] = total;
+}
+
+// The same, split-fp16 form: fragments straight from the [hi | lo] image (rows past the end of the document read on
+// into the next document's tokens — the image is padded by one tile — and are masked by ms_tile_h).
+__global__ __launch_bounds__(256) void maxsim_scores_h_kernel(const unsigned char* __restrict__ img,
+                                                               const long long* __restrict__ doc_ptr, long n_docs,
+                                                               const float* __restrict__ Q, int q_len,
+                                                               float* __restrict__ scores /*[nq, n_docs]*/,
+                                                               float unscale_d) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long doc = (long)blockIdx.x * kMsWaves + wave;
+  if (doc >= n_docs) return;
+  const int qi = blockIdx.y;
+  const int r32 = lane & 31, h = lane >> 5;
+  ms8h qh[8], ql[8];
+  float unscale;
+  ms_load_query_h(Q + (size_t)qi * q_len * kDim, q_len, true, r32, h, qh, ql, unscale);
+  unscale *= unscale_d;
+  const long t_lo = doc_ptr[doc];
+  const int len = (int)(doc_ptr[doc + 1] - t_lo);
+  float best = -FLT_MAX;
+  for (int tok0 = 0; tok0 < len; tok0 += 32) {
+    const unsigned char* p = img + (size_t)(t_lo + tok0 + r32) * 512 + h * 16;
+    ms8h ah[8], al[8];
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      ah[st] = *reinterpret_cast<const ms8h*>(p + 32 * st);
+      al[st] = *reinterpret_cast<const ms8h*>(p + 256 + 32 * st);
+    }
+    ms_tile_h(ah, al, qh, ql, h, len - tok0, best);
+  }
+  const float total = ms_finish_h(best, r32, h, q_len, unscale);
   if (lane == 0) scores[(size_t)qi * n_docs + doc] = total;
 }
 
@@ -257,6 +433,142 @@ __global__ __launch_bounds__(kMsQ * 64) void maxsim_scores_blocked_kernel(const 
 #undef AMDR_MS_STAGE
 }
 
+// ---- ring form of the blocked kernel (split-fp16 tiles) ---------------------------------------------------------
+// A wave's 24 MFMAs of a split-fp16 tile take 768 cycles — less than one trip to L2 / the Infinity Cache — so the
+// one-tile-ahead, register-staged pipeline of the kernel above cannot feed them.  Here the document tiles go through
+// a RING of NBUF 16-KiB LDS stages filled by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write),
+// NBUF - 1 tiles ahead of the one being multiplied:
+//   step s:  s_waitcnt lgkmcnt(0) vmcnt(2 x tiles in flight behind tile s)   this wave's pieces of tile s have landed
+//            s_barrier                                                       ... everybody's; tile s - 1 has been read
+//            DMA of tile s + NBUF - 1 into the stage of tile s - 1
+//            ds_reads of tile s; 24 MFMAs; per-lane maxima; (last tile of a document) the score
+// One raw barrier per tile and no vmcnt(0) in the loop (a __syncthreads() would drain the DMAs in flight); the waits
+// are the s_waitcnt BUILTIN, not inline asm: hipcc's own wait-count pass must see them, or it re-waits in front of
+// the MFMAs.  A DMA lands lane-linear (stage base + lane * 16): the XOR swizzle that makes the ds_read_b128 fragment
+// reads conflict-free is applied to the per-lane SOURCE address (dense_panel.hip does the same).  128 VGPRs and
+// NBUF x 16 KiB of LDS: two blocks = four waves per SIMD per CU, so one block's barrier / DMA wait runs under the
+// other's MFMAs.  Tried on the way (same-box A/B, scripts/ab_maxsim.py): 2 / 3 / 4 / 6 stages 2.55 / 2.31 / 2.24 /
+// 2.44 ms per 1 168 UCC-en queries; 8 / 16 / 32 / 64 documents per block 2.27 / 2.23 / 2.24 / 2.37; a second fragment
+// register set filled one tile ahead (254 VGPRs) +- 0.
+template <int NBUF>
+__global__ __launch_bounds__(kMsQ * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void maxsim_scores_ring_kernel(const unsigned char* __restrict__ img,
+                                                                        const long long* __restrict__ doc_ptr,
+                                                                        long n_docs, int docs_per_block,
+                                                                        const float* __restrict__ Q, int nq, int q_len,
+                                                                        float* __restrict__ scores /*[nq, n_docs]*/,
+                                                                        float unscale_d) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // [NBUF][32 * 512]
+  constexpr int kStage = 32 * 512;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r32 = lane & 31, h = lane >> 5;
+  const int qi = blockIdx.x * kMsQ + wave;
+  const bool live = qi < nq;
+  const long d0 = (long)blockIdx.y * docs_per_block;
+  long d1 = d0 + docs_per_block;
+  if (d1 > n_docs) d1 = n_docs;
+
+  ms8h qh[8], ql[8];
+  float unscale;
+  ms_load_query_h(Q + (size_t)(live ? qi : 0) * q_len * kDim, q_len, live, r32, h, qh, ql, unscale);
+  unscale *= unscale_d;
+
+  // DMA role: piece u (0, 1) of this wave covers stage bytes [(2 wave + u) * 1024, + 1024) = tile rows
+  // 2 (2 wave + u) and + 1; lane l: row + (l >> 5), PHYSICAL slot l & 31, which holds logical slot ^ (row & 15).
+  // poff: the piece's per-lane byte offset inside a tile; rows past the end of a document read on into the next
+  // document's tokens (the image is padded by one tile at its end) and are masked after the MFMAs.
+  long poff[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int prow = 2 * (2 * wave + u) + (lane >> 5);
+    poff[u] = (long)prow * 512 + (((lane & 31) ^ (prow & 15)) << 4);
+  }
+  // fragment read addresses: row r32, chunk 2 s + h (the lo part sits 256 B behind the hi part: slots c and 16 + c
+  // differ in bit 4, which the XOR with row & 15 leaves alone)
+  int foff[8];
+#pragma unroll
+  for (int st = 0; st < 8; ++st) foff[st] = ms_tile_off(r32, 2 * st + h);
+
+  struct Cur {  // a position in the block's tile sequence (wave-uniform)
+    long doc, t_lo;
+    int len, tok0;
+  };
+  auto advance = [&](Cur& c) {
+    c.tok0 += 32;
+    if (c.tok0 >= c.len) {
+      c.doc += 1;
+      c.tok0 = 0;
+      if (c.doc < d1) {
+        c.t_lo = doc_ptr[c.doc];
+        c.len = (int)(doc_ptr[c.doc + 1] - c.t_lo);
+      }
+    }
+  };
+  auto issue = [&](const Cur& c, int stage) {
+    const unsigned char* src = img + (size_t)(c.t_lo + c.tok0) * 512;  // wave-uniform
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      __builtin_amdgcn_global_load_lds(AMDR_MS_GPTR(src + poff[u]),
+                                       AMDR_MS_LPTR(ring + stage * kStage + (2 * wave + u) * 1024), 16, 0, 0);
+  };
+  Cur prod, cur;
+  prod.doc = d0;
+  prod.t_lo = doc_ptr[d0];
+  prod.len = (int)(doc_ptr[d0 + 1] - prod.t_lo);
+  prod.tok0 = 0;
+  cur = prod;
+  int issued = 0, done = 0;
+#pragma unroll
+  for (int i = 0; i < NBUF - 1; ++i) {
+    if (prod.doc < d1) {
+      issue(prod, issued % NBUF);
+      ++issued;
+      advance(prod);
+    }
+  }
+  float best = -FLT_MAX;
+  while (cur.doc < d1) {
+    // simm16 on gfx9: vmcnt [3:0] (+ [15:14]), expcnt [6:4] (7 = none), lgkmcnt [11:8].  lgkmcnt(0) on every path as
+    // ONE unconditional instruction (inside the branches below the pass still re-waited in front of the MFMAs);
+    // this wave's pieces of tile `done` have landed once at most 2 x (tiles issued after it) loads are outstanding.
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    const int behind = issued - done - 1;
+    if (behind >= 3) {
+      __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(6)
+    } else if (behind == 2) {
+      __builtin_amdgcn_s_waitcnt(0x0F74);
+    } else if (behind == 1) {
+      __builtin_amdgcn_s_waitcnt(0x0F72);
+    } else {
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (prod.doc < d1) {
+      issue(prod, issued % NBUF);
+      ++issued;
+      advance(prod);
+    }
+    const unsigned char* tile = ring + (done % NBUF) * kStage;
+    ms8h ah[8], al[8];
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      const unsigned char* fp = tile + foff[st];
+      ah[st] = *reinterpret_cast<const ms8h*>(fp);
+      al[st] = *reinterpret_cast<const ms8h*>(fp + 256);
+    }
+    const int remain = cur.len - cur.tok0;
+    ms_tile_h(ah, al, qh, ql, h, remain, best);
+    if (remain <= 32) {  // last tile of this document
+      const float total = ms_finish_h(best, r32, h, q_len, unscale);
+      if (live && lane == 0) scores[(size_t)qi * n_docs + cur.doc] = total;
+      best = -FLT_MAX;
+    }
+    ++done;
+    advance(cur);
+  }
+}
+
 // Per-query top-k over a dense fp32 score row (one block per query).
 __global__ __launch_bounds__(256) void rowscores_topk_kernel(const float* __restrict__ scores, long n, int k, int cap,
                                                               float* __restrict__ out_scores,
@@ -295,6 +607,8 @@ struct amdr_maxsim {
   int device = 0;
   int64_t n_docs = 0, n_tokens = 0;
   float* D = nullptr;
+  unsigned char* img = nullptr;  // [hi 128 x fp16 | lo 128 x fp16] per token, scaled by d_scale (split-fp16 form)
+  float d_scale = 1.f;           // power of two; img == nullptr: the store is not finite -> fp32-input form only
   long long* doc_ptr = nullptr;
   hipStream_t stream = nullptr;
   std::mutex mu;
@@ -305,14 +619,46 @@ namespace {
 
 int ms_run(amdr_maxsim* h, const float* Q_dev, int nq, int q_len, int k, float* full_dev, float* scores_dev,
            int64_t* ids_dev, hipStream_t st) {
-  if (nq >= kMsQ && ceil_div(h->n_docs, kMsDocs) <= 65535) {  // batches: document tiles shared by 8 queries through LDS
+  const char* pin = getenv("AMDR_MAXSIM_F16X3");
+  const bool half = h->img != nullptr && !(pin && pin[0] == '0');  // split-fp16 MFMA form (default) / fp32-input form
+  const float unscale_d = 1.f / h->d_scale;
+  const bool batch = nq >= kMsQ;  // batches: document tiles shared by 8 queries through LDS
+  if (batch && half) {
+    const char* rg = getenv("AMDR_MAXSIM_RING");  // LDS stages (2 / 3 / 4 / 6; measured best: 4)
+    const int nbuf = rg ? atoi(rg) : 4;
+    const char* dpb = getenv("AMDR_MAXSIM_DOCS");  // documents per block (measured best: 16)
+    long docs = dpb && atoi(dpb) > 0 ? atoi(dpb) : 16;
+    while (ceil_div(h->n_docs, docs) > 65535) docs *= 2;
+    dim3 grid(ceil_div(nq, kMsQ), ceil_div(h->n_docs, docs));
+#define AMDR_MS_RING(NB)                                                                                             \
+  {                                                                                                                  \
+    AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_scores_ring_kernel<NB>,                                         \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, NB * 16384));                           \
+    hipLaunchKernelGGL((maxsim_scores_ring_kernel<NB>), grid, dim3(kMsQ * 64), NB * 16384, st, h->img, h->doc_ptr,    \
+                       (long)h->n_docs, (int)docs, Q_dev, nq, q_len, full_dev, unscale_d);                           \
+  }
+    if (nbuf == 2) {
+      AMDR_MS_RING(2)
+    } else if (nbuf == 3) {
+      AMDR_MS_RING(3)
+    } else if (nbuf == 6) {
+      AMDR_MS_RING(6)
+    } else {
+      AMDR_MS_RING(4)
+    }
+#undef AMDR_MS_RING
+  } else if (batch && ceil_div(h->n_docs, kMsDocs) <= 65535) {
     dim3 grid(ceil_div(nq, kMsQ), ceil_div(h->n_docs, kMsDocs));
     hipLaunchKernelGGL(maxsim_scores_blocked_kernel, grid, dim3(kMsQ * 64), 0, st, h->D, h->doc_ptr, (long)h->n_docs,
                        (long)h->n_tokens, Q_dev, nq, q_len, full_dev);
   } else {
     dim3 grid(ceil_div(h->n_docs, kMsWaves), nq);
-    hipLaunchKernelGGL(maxsim_scores_kernel, grid, dim3(256), 0, st, h->D, h->doc_ptr, (long)h->n_docs, Q_dev, q_len,
-                       full_dev);
+    if (half)
+      hipLaunchKernelGGL(maxsim_scores_h_kernel, grid, dim3(256), 0, st, h->img, h->doc_ptr, (long)h->n_docs, Q_dev,
+                         q_len, full_dev, unscale_d);
+    else
+      hipLaunchKernelGGL(maxsim_scores_kernel, grid, dim3(256), 0, st, h->D, h->doc_ptr, (long)h->n_docs, Q_dev, q_len,
+                         full_dev);
   }
   AMDR_HIP(hipGetLastError());
   if (scores_dev) {
@@ -362,6 +708,31 @@ int amdr_maxsim_create(const float* D_host, const int64_t* doc_ptr, int64_t n_do
   if (e == hipSuccess)
     e = hipMemcpy(h->doc_ptr, doc_ptr, (size_t)(n_docs + 1) * sizeof(long long), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  // the split-fp16 image: the store's largest |component| fixes a power-of-two scale into [0.5, 1), then every
+  // token row is split once (a store with a NaN / infinity keeps the fp32-input form only)
+  unsigned int* mx = nullptr;
+  unsigned int mbits = 0;
+  if (e == hipSuccess) e = hipMalloc((void**)&mx, sizeof(unsigned int));
+  if (e == hipSuccess) e = hipMemset(mx, 0, sizeof(unsigned int));
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(ms_absmax_kernel, dim3(1024), dim3(256), 0, 0, h->D, (long)(nt * dim), mx);
+    e = hipMemcpy(&mbits, mx, sizeof(unsigned int), hipMemcpyDeviceToHost);
+  }
+  if (mx) (void)hipFree(mx);
+  if (e == hipSuccess && mbits < 0x7f800000u) {
+    float m;
+    memcpy(&m, &mbits, sizeof(float));
+    int ex = 0;
+    if (m > 0.f) (void)frexpf(m, &ex);
+    h->d_scale = ldexpf(1.f, -ex);
+    e = hipMalloc((void**)&h->img, (size_t)(nt + 32) * 512);  // + one tile: the last tile of the last document reads on
+    if (e == hipSuccess) e = hipMemset(h->img + (size_t)nt * 512, 0, (size_t)32 * 512);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(ms_split_store_kernel, dim3(ceil_div(nt * 16, 256)), dim3(256), 0, 0, h->D, (long)nt, h->d_scale,
+                         h->img);
+      e = hipDeviceSynchronize();
+    }
+  }
   if (e != hipSuccess) {
     amdr_maxsim_destroy(h);
     return fail(e == hipErrorOutOfMemory ? AMDR_ENOMEM : AMDR_EHIP, "maxsim_create: %s", hipGetErrorString(e));
@@ -373,6 +744,21 @@ int amdr_maxsim_create(const float* D_host, const int64_t* doc_ptr, int64_t n_do
 int amdr_maxsim_ndocs(const amdr_maxsim_t* h, int64_t* n) {
   AMDR_REQUIRE(h && n, "maxsim_ndocs: null");
   *n = h->n_docs;
+  return AMDR_OK;
+}
+
+int amdr_maxsim_plan_info(const amdr_maxsim_t* h, int32_t nq, char* buf, int32_t buf_len) {
+  AMDR_REQUIRE(h && buf && buf_len > 0, "maxsim_plan_info: null");
+  AMDR_REQUIRE(nq >= 1, "maxsim_plan_info: nq=%d", nq);
+  const char* pin = getenv("AMDR_MAXSIM_F16X3");
+  const bool half = h->img != nullptr && !(pin && pin[0] == '0');
+  const bool batch = nq >= kMsQ;
+  if (half)
+    snprintf(buf, buf_len, "%s split-fp16 (hi + lo/2048, 3 x v_mfma_f32_32x32x16_f16 per block) + rowscores_topk_kernel",
+             batch ? "maxsim_scores_ring_kernel" : "maxsim_scores_h_kernel");
+  else
+    snprintf(buf, buf_len, "%s fp32-input (v_mfma_f32_16x16x4_f32) + rowscores_topk_kernel",
+             batch ? "maxsim_scores_blocked_kernel" : "maxsim_scores_kernel");
   return AMDR_OK;
 }
 
@@ -450,6 +836,7 @@ int amdr_maxsim_destroy(amdr_maxsim_t* h) {
     (void)hipStreamDestroy(h->stream);
   }
   if (h->D) (void)hipFree(h->D);
+  if (h->img) (void)hipFree(h->img);
   if (h->doc_ptr) (void)hipFree(h->doc_ptr);
   h->full[0].release();
   h->full[1].release();

@@ -593,6 +593,70 @@ def test_maxsim_blocked_equals_per_query_bitwise(nat):
     assert np.array_equal(batch, single)
 
 
+def test_maxsim_split_fp16_form_accuracy_scaling_and_pin(nat, monkeypatch):
+    """The default MaxSim form runs the tile on v_mfma_f32_16x16x32_f16 with every operand split exactly into
+    hi + lo / 2048 (22 significant bits, three MFMAs per block; csrc/maxsim.hip); AMDR_MAXSIM_F16X3=0 pins the
+    fp32-input MFMA form.  Against the fp64 oracle the split form must stay FAR inside north_star's 1e-4 (a few 1e-6
+    on scores of ~20 — no worse than the fp32-input form, whose 128-term fp32 chains round more often); the two forms
+    agree to 2e-5; both kernels (blocked / per pair) return the same bits in either form; power-of-two scaling makes
+    the result scale-free: a store 37.5 x larger and queries 1/1024 x smaller give the same relative errors, a store
+    with wildly different token norms stays accurate relative to its largest token; a non-finite store falls back to
+    the fp32-input form instead of poisoning a scale."""
+    from oracle import maxsim as OM
+    rng = np.random.default_rng(77)
+    n_docs, nq, q_len = 150, 24, 32
+    lens = rng.integers(1, 221, size=n_docs)
+    lens[:6] = [1, 15, 16, 17, 32, 220]
+    doc_ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    D = unit_rows(rng, int(doc_ptr[-1]), 128)
+    Q = unit_rows(rng, nq * q_len, 128).reshape(nq, q_len, 128)
+    ref = OM.maxsim_scores(Q, D, doc_ptr)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("AMDR_MAXSIM_F16X3", flag)
+        idx = nat.MaxSimIndex(D, doc_ptr)
+        out[flag] = idx.scores(Q)
+        single = np.concatenate([idx.scores(Q[b:b + 1]) for b in range(0, nq, 5)])
+        assert np.array_equal(out[flag][::5], single), flag  # blocked == per-pair kernel, bit for bit
+        idx.close()
+    e_half, e_f32 = np.max(np.abs(out["1"] - ref)), np.max(np.abs(out["0"] - ref))
+    assert e_half <= 1e-5 and e_f32 <= 2e-5, (e_half, e_f32)
+    assert not np.array_equal(out["1"], out["0"])  # the pin really selects another kernel
+    assert np.max(np.abs(out["1"] - out["0"])) <= 2e-5
+    monkeypatch.setenv("AMDR_MAXSIM_F16X3", "1")
+    # scale-free: the same data, store x 37.5 (not a power of two), queries / 1024
+    idx = nat.MaxSimIndex((D * np.float32(37.5)).astype(np.float32), doc_ptr)
+    got = idx.scores((Q / np.float32(1024)).astype(np.float32))
+    idx.close()
+    ref_s = OM.maxsim_scores((Q / np.float32(1024)).astype(np.float32), (D * np.float32(37.5)).astype(np.float32), doc_ptr)
+    assert np.max(np.abs(got - ref_s)) <= 1e-5 * 37.5 / 1024
+    # token norms spread over 2^-10 .. 1: error stays relative to the LARGEST token (fixed-point-like), inside 1e-4
+    w = np.exp2(-rng.integers(0, 11, size=D.shape[0])).astype(np.float32)[:, None]
+    idx = nat.MaxSimIndex(D * w, doc_ptr)
+    got = idx.scores(Q)
+    idx.close()
+    assert np.max(np.abs(got - OM.maxsim_scores(Q, D * w, doc_ptr))) <= 1e-5
+    # a query block with an all-zero query and a tiny one
+    Qz = Q.copy()
+    Qz[3] = 0.0
+    Qz[4] *= np.float32(1e-30)
+    idx = nat.MaxSimIndex(D, doc_ptr)
+    got = idx.scores(Qz)
+    assert np.all(got[3] == 0.0) and np.allclose(got[4], ref[4] * 1e-30, rtol=1e-5, atol=0)
+    assert np.max(np.abs(got[5:] - ref[5:])) <= 1e-5
+    idx.close()
+    # a store holding an infinity: no scale can be taken from it -> fp32-input form (results as before)
+    Dn = D.copy()
+    Dn[7, 3] = np.inf
+    idx = nat.MaxSimIndex(Dn, doc_ptr)
+    got = idx.scores(Q[:8])
+    idx.close()
+    bad = int(np.searchsorted(doc_ptr, 7, side="right") - 1)
+    ok = np.ones(n_docs, bool)
+    ok[bad] = False
+    assert np.max(np.abs(got[:, ok] - ref[:8, ok])) <= 2e-5 and not np.isfinite(got[:, bad]).all()
+
+
 def test_maxsim_fuzz_vs_oracle(nat):
     """Seeded sweep of both MaxSim forms (per-pair for < 8 queries, blocked otherwise): ragged
     document lengths around the 32-token tile, document counts around the 8-document group,
