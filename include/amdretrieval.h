@@ -46,6 +46,7 @@ extern "C" {
 typedef struct amdr_dense amdr_dense_t;
 typedef struct amdr_bm25 amdr_bm25_t;
 typedef struct amdr_maxsim amdr_maxsim_t;
+typedef struct amdr_tokenizer amdr_tokenizer_t;
 
 /* ---- library ---------------------------------------------------------- */
 const char* amdr_last_error(void);
@@ -121,6 +122,23 @@ int amdr_bm25_search_device(amdr_bm25_t* h, const int32_t* q_terms_dev, const in
 int amdr_bm25_scores(amdr_bm25_t* h, const int32_t* q_terms, const int64_t* q_ptr, int32_t nq,
                      double* scores_host);
 int amdr_bm25_destroy(amdr_bm25_t* h);
+
+/* ---- BM25 query tokeniser + vocabulary lookup, batched (host code) -------
+ * Replaces, per query, `tokens = list(jieba.cut(query))` and the per-token vocabulary lookup of
+ * `BM25Okapi.get_scores` (legalrag/retrieval/bm25_retriever.py:73-74) for text WITHOUT Han characters — the
+ * case jieba's default mode decides without its dictionary (rule: legal-rag_amd/text.py, which stays the executable
+ * specification; csrc/tokenize.cpp).  Queries are not lower-cased (the reference does not).  A query holding a Han
+ * character is not tokenised: needs_segmenter[q] = 1, it gets no terms, and the caller takes its own segmenter.
+ * vocab: n_terms UTF-8 strings, term i = vocab_blob[vocab_offsets[i] .. vocab_offsets[i+1]).
+ * encode: queries as one UTF-8 blob + offsets [nq+1]; writes the CSR amdr_bm25_search takes — term_ids (capacity:
+ * the blob's byte length always suffices; unknown token = -1) and q_ptr [nq+1].  No device work; thread-safe. */
+int amdr_tokenizer_create(const char* vocab_blob, const int64_t* vocab_offsets, int64_t n_terms, amdr_tokenizer_t** out);
+int amdr_tokenizer_encode(const amdr_tokenizer_t* t, const char* text_blob, const int64_t* text_offsets, int32_t nq,
+                          int32_t* term_ids, int64_t capacity, int64_t* q_ptr, int32_t* needs_segmenter);
+/* byte spans of one text's tokens (tests compare them with text.jieba_cut); *n_tokens = -1: Han text */
+int amdr_tokenizer_spans(const char* text, int64_t n_bytes, int32_t* starts, int32_t* ends, int32_t capacity,
+                         int32_t* n_tokens);
+int amdr_tokenizer_destroy(amdr_tokenizer_t* t);
 
 /* ---- ColBERT channel: exhaustive late-interaction MaxSim ---------------
  * Replaces `Searcher.search(query, k)` (legalrag/retrieval/colbert_retriever.py:152).

@@ -85,6 +85,43 @@ class BM25Retriever:
         self._tls.exact = not (text.contains_han(query) and (self.index_tokenizer == "char" or not text.zh_exact()))
         return toks
 
+    def term_ids_batch(self, questions: Sequence[str]):
+        """Tokenise + look up a whole batch: (q_terms i32, q_ptr i64 [n+1], exact bool [n]) — the query CSR of
+        amdr_bm25_search.  Text without Han characters goes through the native batched tokeniser (one call, GIL
+        released: amdr_tokenizer_encode, token for token what text.jieba_cut returns for it); a query holding Han
+        characters — and every query when jieba or a registered segmenter is present — takes tokenize_query()."""
+        import numpy as np
+        from .. import _native
+        self.load()
+        n = len(questions)
+        native_ok = text._custom_cut is None and not text.HAVE_JIEBA
+        if native_ok:
+            tok = self.__dict__.get("_native_tok")
+            if tok is None or tok[0] is not self.bm25:
+                tok = (self.bm25, _native.Tokenizer(list(self.bm25.vocab().keys())))
+                self.__dict__["_native_tok"] = tok
+            terms, q_ptr, hard = tok[1].encode([q or "" for q in questions])
+            exact = np.full(n, self.index_tokenizer != "char", dtype=bool)
+            if not hard.any():
+                return terms, q_ptr, exact
+        else:
+            hard = np.ones(n, dtype=bool)
+            terms, q_ptr = np.zeros(0, np.int32), np.zeros(n + 1, np.int64)
+            exact = np.ones(n, dtype=bool)
+        # the remaining queries one by one, spliced into the CSR
+        parts, lens = [], np.diff(q_ptr)
+        for i in range(n):
+            if hard[i]:
+                ids = np.asarray(self.bm25.term_ids(self.tokenize_query(questions[i])), dtype=np.int32)
+                exact[i] = self.zh_exact
+                lens[i] = len(ids)
+                parts.append(ids)
+            else:
+                parts.append(terms[q_ptr[i]:q_ptr[i + 1]])
+        out_ptr = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(lens, out=out_ptr[1:])
+        return (np.concatenate(parts).astype(np.int32) if parts else np.zeros(0, np.int32)), out_ptr, exact
+
     @property
     def zh_exact(self) -> bool:
         """False when this thread's last query (or the index itself) went through the

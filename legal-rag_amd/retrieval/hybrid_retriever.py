@@ -507,7 +507,8 @@ class HybridRetriever:
         return HybridEngine(store.index.native, bm.gpu_index(), col._searcher if col is not None else None,
                             device=dev, shard_offset=offset, shard_group=shard.group if shard is not None else None)
 
-    def _batch_native(self, questions: Sequence[str], eff: int, native, min_final: float, arrays: bool = False):
+    def _batch_native(self, questions: Sequence[str], eff: int, native, min_final: float, arrays: bool = False,
+                      q_emb=None):
         """Embed / tokenise on the host, then dense + BM25 (+ MaxSim) top-k -> fuse -> min_final
         count for the whole batch on torch's current stream, one synchronise, results built once.
         Returns ([fused hits with score >= min_final per question], (t_after_dense_prep, t_after_bm25_prep,
@@ -526,19 +527,24 @@ class HybridRetriever:
                 raise ValueError("search_batch_arrays: empty questions are not supported in the columnar form")
             for idxs, nat in ((blank, (store, bm, None)), (rest, native)):
                 if idxs:
-                    part, stamps = self._batch_native([questions[i] for i in idxs], eff, nat, min_final)
+                    part, stamps = self._batch_native([questions[i] for i in idxs], eff, nat, min_final,
+                                                      q_emb=None if q_emb is None else q_emb[idxs])
                     for i, h in zip(idxs, part):
                         out[i] = h
             return out, stamps
         dev = int(getattr(self.cfg.retrieval, "device", 0))
         tdev = torch.device("cuda", dev)
-        q_emb = store.embed_device(list(questions), is_query=True)  # encoder output stays in HBM
+        if q_emb is None:
+            q_emb = store.embed_device(list(questions), is_query=True)  # encoder output stays in HBM
+        else:  # the caller's own encoder output (numpy or a device tensor), one row per question
+            q_emb = (torch.from_numpy(np.ascontiguousarray(q_emb, dtype=np.float32)) if isinstance(q_emb, np.ndarray)
+                     else q_emb).to(tdev, dtype=torch.float32, non_blocking=True).contiguous()
+            if q_emb.shape != (len(questions), store.index.d):
+                raise ValueError(f"q_emb must be [{len(questions)}, {store.index.d}], got {tuple(q_emb.shape)}")
         t1 = time.time()
-        tids, exact = [], []
-        for q in questions:
-            tids.append(bm.bm25.term_ids(bm.tokenize_query(q)))
-            exact.append(bm.zh_exact)
-        qt, qp = _native.BM25Index.pack_queries(tids)
+        qt, qp, exact = bm.term_ids_batch(questions)  # native batched tokeniser + vocabulary lookup
+        if qt.size == 0:
+            qt = np.zeros(1, dtype=np.int32)  # pack_queries' convention for "no term at all"
         t2 = time.time()
         q_tok_h = None
         if col is not None:
@@ -591,7 +597,7 @@ class HybridRetriever:
 
     # ----------------------------------------------------------- batch form
     def search_batch(self, questions: Sequence[str], top_k: int = 10, llm: Any = None,
-                     decisions: Optional[Sequence[Any]] = None) -> List[List[RetrievalHit]]:
+                     decisions: Optional[Sequence[Any]] = None, q_emb=None) -> List[List[RetrievalHit]]:
         """Throughput form: `search_batch(qs)[i]` == `search(qs[i])` for every stage the configuration enables
         (hybrid_retriever.py:282-384) — one kernel pipeline for the whole batch (dense + BM25 (+ ColBERT) -> fuse
         -> filter), the graph stage per query whose `decisions[i]` asks for it, the rerank stage with the
@@ -606,7 +612,7 @@ class HybridRetriever:
         if native is None:
             raise RuntimeError("search_batch requires this package's own dense / BM25 (/ ColBERT) retrievers built "
                                "over the same chunk list")
-        outs, _ = self._batch_native(questions, eff, native, float(getattr(rcfg, "min_final_score", 0.0)))
+        outs, _ = self._batch_native(questions, eff, native, float(getattr(rcfg, "min_final_score", 0.0)), q_emb=q_emb)
         if getattr(rcfg, "enable_graph", False) and decisions is not None:
             seed_n = int(getattr(rcfg, "graph_seed_k", max(10, top_k * 3)))
             for i, dec in enumerate(decisions):
@@ -617,10 +623,12 @@ class HybridRetriever:
             outs = self._rerank_stage(questions, outs, llm, top_k)
         return [_dedup_keep_best(hits)[:top_k] for hits in outs]
 
-    def search_batch_arrays(self, questions: Sequence[str], top_k: int = 10) -> Dict[str, Any]:
+    def search_batch_arrays(self, questions: Sequence[str], top_k: int = 10, q_emb=None) -> Dict[str, Any]:
         """`search_batch` without building RetrievalHit objects (pydantic construction, not the GPU, bounds
         `search_batch` at a few thousand queries/s): columnar results for bulk callers (evaluation sweeps,
         offline scoring).  rows[q, j] indexes `self.dense.store.chunks`; entries j >= count[q] are -1 / 0.
+        `q_emb` ([n, d] numpy array or device tensor): query embeddings the caller's encoder already produced
+        (a deployment batches its BERT forward itself); default: this store's encoder.
         The rows of one index are distinct chunks, so the dedup step of search() has nothing to merge."""
         rcfg = self.cfg.retrieval
         top_k = max(1, int(top_k))
@@ -629,7 +637,8 @@ class HybridRetriever:
         if native is None:
             raise RuntimeError("search_batch_arrays requires this package's own retrievers built over the same chunk list")
         (ids, vals, mask, cnt, exact), _ = self._batch_native(list(questions), eff, native,
-                                                                float(getattr(rcfg, "min_final_score", 0.0)), arrays=True)
+                                                                float(getattr(rcfg, "min_final_score", 0.0)), arrays=True,
+                                                                q_emb=q_emb)
         w = min(top_k, ids.shape[1])
         keep = np.arange(w)[None, :] < np.minimum(cnt, w)[:, None]
         return {"rows": np.where(keep, ids[:, :w], -1), "scores": np.where(keep, vals[:, :w, _native.FV["score"]], 0.0),

@@ -427,6 +427,34 @@ def test_search_batch_arrays_equals_search_batch(ucc_index):
         r.search_batch_arrays(["ok", "  "], top_k=5)
 
 
+def test_batch_tokeniser_and_caller_supplied_embeddings(ucc_index, monkeypatch):
+    """search_batch_arrays tokenises the whole batch in one native call (BM25Retriever.term_ids_batch) and accepts the
+    caller's own query embeddings: both must give exactly what the per-query Python path gives."""
+    from legal_rag_amd import text
+    from legal_rag_amd.retrieval.hybrid_retriever import HybridRetriever
+    cfg, _ = ucc_index
+    cfg2 = copy.deepcopy(cfg)
+    cfg2.retrieval.enable_rerank = False
+    r = HybridRetriever(cfg2)
+    qs = QUESTIONS * 3 + ["What is § 2-314?", "rate of 3.5% p.a. (a) C++", "x"]
+    terms, q_ptr, exact = r.bm25.term_ids_batch(qs)
+    assert exact.all() and q_ptr[-1] == len(terms)
+    for i, q in enumerate(qs):
+        assert terms[q_ptr[i]:q_ptr[i + 1]].tolist() == r.bm25.bm25.term_ids(text.jieba_cut(q))
+    base = r.search_batch_arrays(qs, top_k=10)
+    emb = r.dense.store._embed(qs, is_query=True)
+    for q_emb in (emb, __import__("torch").from_numpy(emb).cuda()):
+        got = r.search_batch_arrays(qs, top_k=10, q_emb=q_emb)
+        assert np.array_equal(got["rows"], base["rows"]) and np.array_equal(got["scores"], base["scores"])
+    with pytest.raises(ValueError, match="q_emb must be"):
+        r.search_batch_arrays(qs, top_k=10, q_emb=emb[:3])
+    # with a registered segmenter every query goes through it (the native rule is only jieba's no-dictionary case)
+    calls = []
+    monkeypatch.setattr(text, "_custom_cut", lambda s_: calls.append(s_) or text.jieba_cut_restated(s_))
+    t2, p2, _ = r.bm25.term_ids_batch(qs[:4])
+    assert len(calls) == 4 and np.array_equal(t2, terms[: q_ptr[4]]) and np.array_equal(p2, q_ptr[:5])
+
+
 def test_error_conventions(tmp_path):
     """Missing dense files -> FileNotFoundError; missing bm25 -> RuntimeError;
     missing colbert meta is swallowed at construction."""

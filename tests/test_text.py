@@ -116,3 +116,59 @@ def test_bm25_builder_refuses_han_without_segmenter_and_records_tokenizer(tmp_pa
     assert bm.__dict__["_tokenizer_id"] == "jieba-offline" and "当事人" in bm.idf and bm.doc_len == [3, 6]
     with pytest.raises(ValueError):
         build_bm25_index(cfg, chunks, tokens=[["x"]])
+
+
+# ---- native batched tokeniser (csrc/tokenize.cpp): token for token what text.jieba_cut returns for non-Han text ----
+NATIVE_CASES = ["What is § 2-314?", "rate of 3.5% p.a.", "a--b", "x", "", "tab\there\r\nnext", "C++ and AT&T",
+                "(a) buyer", "1.2.3 a1.5b 50%.x  é—ü\u3000z", "c#c++x AT&T&", "AT&TC++C#", "a.b.c 1.%  2.5%% _x_ -- + #",
+                "\r\n\r \n\x0b\x0c\x1c\x85\xa0\u2003\u2028end", "UPPER lower MiXeD 007", "§§ 9-102(a)(1)—“goods”",
+                "trailing.", ".leading", "100%", "%", "a" * 300]
+
+
+@pytest.mark.parametrize("q", NATIVE_CASES)
+def test_native_tokenizer_equals_python_rule(q):
+    from legal_rag_amd import _native
+    assert _native.Tokenizer.cut(q) == text.jieba_cut_restated(q)
+
+
+def test_native_tokenizer_on_the_ucc_queries_and_corpus_and_fuzz():
+    """Every query of the 1 168-query UCC-en evaluation set, every chunk text of the corpus, and a seeded fuzz over
+    an alphabet of letters, digits, the block punctuation, the dictionary marks, ASCII / Unicode whitespace and
+    non-ASCII symbols: identical token lists."""
+    import numpy as np
+    from conftest import GOLDEN
+    from legal_rag_amd import _native
+    from legal_rag_amd.evaluation import synthetic_queries
+    from legal_rag_amd.retrieval.corpus_loader import load_chunks_from_dir
+    chunks = load_chunks_from_dir(str(GOLDEN / "corpus"), "law_en.jsonl")
+    qs = [q for q, _, _ in synthetic_queries(chunks, seed=0)]
+    assert len(qs) == 1168
+    for t in qs + [c.text for c in chunks[::7]]:
+        assert _native.Tokenizer.cut(t) == text.jieba_cut_restated(t), t[:80]
+    rng = np.random.default_rng(11)
+    alphabet = list("abcXYZ0159") + list("+#&._%-") * 2 + list(" \t\n\r") + ["\r\n", "§", "é", "\u3000", "\xa0", "(", ")", ",", "C++", "AT&T", "c#"]
+    for _ in range(3000):
+        t = "".join(alphabet[i] for i in rng.integers(0, len(alphabet), size=int(rng.integers(0, 40))))
+        assert _native.Tokenizer.cut(t) == text.jieba_cut_restated(t), repr(t)
+    assert _native.Tokenizer.cut("第四百九十五条 contract") is None  # Han text is never cut by the native rule
+
+
+def test_native_encode_is_the_term_id_csr_of_the_python_path():
+    import numpy as np
+    from legal_rag_amd import _native
+    from legal_rag_amd.bm25_model import BM25Okapi
+    docs = [text.tokenize_en(t) for t in ("The buyer may reject goods.", "Merchant means a person; 3.5% rate", "c++ and AT&T § 2-314")]
+    docs.append(["C++", "§", " ", "AT&T", "--"])  # tokens only the query-side rule produces
+    bm = BM25Okapi(docs)
+    tok = _native.Tokenizer(list(bm.vocab().keys()))
+    qs = ["the buyer may reject", "The Buyer", "", "3.5% rate of C++ -- AT&T", "合同 buyer", "goods.  §", "   "]
+    terms, q_ptr, hard = tok.encode(qs)
+    assert hard.tolist() == [False, False, False, False, True, False, False]
+    assert q_ptr[0] == 0 and q_ptr[-1] == len(terms)
+    for i, q in enumerate(qs):
+        got = terms[q_ptr[i]:q_ptr[i + 1]].tolist()
+        assert got == ([] if hard[i] else bm.term_ids(text.jieba_cut_restated(q))), q
+    assert (terms >= -1).all() and (terms < len(bm.vocab())).all() and (terms == -1).any()
+    ids, ptr = _native.BM25Index.pack_queries([bm.term_ids(text.jieba_cut_restated(q)) for q in qs if not text.contains_han(q)])
+    keep = [i for i in range(len(qs)) if not hard[i]]
+    assert np.array_equal(np.concatenate([terms[q_ptr[i]:q_ptr[i + 1]] for i in keep]), ids[: ptr[-1]])
