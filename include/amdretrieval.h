@@ -214,6 +214,18 @@ int amdr_fuse_device(const amdr_fuse_params_t* p, int32_t nq,
                      int64_t* out_ids, double* out_vals, int32_t* out_mask, int32_t* out_count,
                      int32_t device, void* stream);
 
+/* amdr_dense_search_device followed by amdr_fuse_device(dense lists, BM25 lists, no ColBERT) as ONE call — the same
+ * outputs, bit for bit (dense_scores / dense_ids: the dense channel's own top-k; out_*: the fusion's), fewer launches:
+ * for the serving corpora under a batch (<= 1 024 rows, k + kb <= 32) the rows are ranked and fused by one kernel
+ * (two queries per wave), every other shape runs the two launches inside.  Reference stages:
+ * hybrid_retriever.py:181-189 (search_dense) + :389-551 (_fuse).  AMDR_DENSE_FUSE=0 pins the two launches. */
+int amdr_dense_search_fuse_device(amdr_dense_t* h, const float* Q_dev, int32_t nq, int32_t k,
+                                  const amdr_fuse_params_t* p, const int64_t* dense_row2uid,
+                                  const int64_t* bm25_ids, const double* bm25_scores, int32_t kb,
+                                  const int64_t* bm25_row2uid, float* dense_scores_dev, int64_t* dense_ids_dev,
+                                  int64_t* out_ids, double* out_vals, int32_t* out_mask, int32_t* out_count,
+                                  void* stream);
+
 /* Rerank blend over the first min(top_n, count[q]) fused hits of each query:
  * norm = minmax(ce_raw); score = (1-beta)*score + beta*norm; the candidates
  * are re-ordered by norm (stable), written back in front of the rest, and the

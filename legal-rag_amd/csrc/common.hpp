@@ -93,6 +93,28 @@ int dense_mfma_launch_topk(const DenseMfmaPlan& p, const float* S, long n, int n
                            float* fin_scores, int64_t* fin_ids, hipStream_t st);
 
 
+// ---- dense top-k + fusion in one call (fuse.hip; dense.hip amdr_dense_search_fuse_device) ----
+struct FuseTail {  // the fusion that follows the dense channel: parameters, the BM25 lists, the outputs (device pointers)
+  const amdr_fuse_params_t* p;
+  const int64_t* dense_row2uid;
+  const int64_t* bm25_ids;
+  const double* bm25_scores;
+  int kb;
+  const int64_t* bm25_row2uid;
+  int64_t* out_ids;
+  double* out_vals;
+  int32_t* out_mask;
+  int32_t* out_count;
+};
+// one kernel ranks the rows of S and fuses (dense_select_fuse_kernel): single slab, <= 1 024 rows, kd + kb <= 32
+bool dense_select_fuse_applies(long n, int slabs, int m, int kd, int kb);
+// queries [q0, q0 + m) of the batch: S holds their score rows; writes their dense lists and their fused outputs
+int dense_select_fuse_launch(const FuseTail& t, int q0, const float* S, long ldS, long n, int m, int kd, int cap,
+                             float* fin_scores, int64_t* fin_ids, hipStream_t st);
+// the plain fusion launch over finished dense lists (the unfused path of the same call)
+int dense_fuse_plain_launch(const FuseTail& t, int q0, int m, int kd, const float* dense_scores, const int64_t* dense_ids,
+                            hipStream_t st);
+
 // ---- long-batch dense path: dense_panel.hip (panel of chunk rows shared by a block through LDS) ----
 struct DensePanelPlan {
   int parts, base, rem, nb, m_tiles, gm, waves;

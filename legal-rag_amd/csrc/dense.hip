@@ -414,7 +414,7 @@ size_t batched_part_need(const amdr_dense* h, int nq, int k) {
 // Two-pass form: scores S[q][row] (fp32-MFMA tiles for batches, one wave per (query, row) for the
 // 1-4 query call on a short corpus), then slab top-k (+ merge when there are several slabs).
 int run_search_batched(amdr_dense* h, int ws, const float* Q_dev, int nq, int k, float* scores_dev, int64_t* ids_dev,
-                       hipStream_t st, bool row_waves = false) {
+                       hipStream_t st, bool row_waves = false, const FuseTail* tail = nullptr) {
   DevBuf& smat = h->smat[ws];
   DevBuf& partb = h->part[ws];
   const int chunk = batched_chunk(h, nq);
@@ -447,6 +447,13 @@ int run_search_batched(amdr_dense* h, int ws, const float* Q_dev, int nq, int k,
       h->prof_used += 2;
     }
     const bool direct = p.slabs == 1;  // one slab: its list is the answer, no merge launch
+    if (tail && dense_select_fuse_applies((long)h->n, p.slabs, m, k, tail->kb)) {
+      // ranking of the rows and the fusion with the BM25 lists in one kernel (fuse.hip dense_select_fuse_kernel)
+      if ((rc = dense_select_fuse_launch(*tail, q0, smat.as<float>(), p.ld, (long)h->n, m, k, p.cap,
+                                         scores_dev + (size_t)q0 * k, ids_dev + (size_t)q0 * k, st)))
+        return rc;
+      continue;
+    }
     rc = dense_mfma_launch_topk(p, smat.as<float>(), (long)h->n, m, k, partb.p,
                                 direct ? scores_dev + (size_t)q0 * k : nullptr,
                                 direct ? ids_dev + (size_t)q0 * k : nullptr, st);
@@ -457,6 +464,8 @@ int run_search_batched(amdr_dense* h, int ws, const float* Q_dev, int nq, int k,
                          scores_dev + (size_t)q0 * k, (long long*)ids_dev + (size_t)q0 * k);
       AMDR_HIP(hipGetLastError());
     }
+    if (tail && (rc = dense_fuse_plain_launch(*tail, q0, m, k, scores_dev + (size_t)q0 * k, ids_dev + (size_t)q0 * k, st)))
+      return rc;
   }
   return AMDR_OK;
 }
@@ -786,6 +795,28 @@ int amdr_dense_search_device(amdr_dense_t* h, const float* Q_dev, int32_t nq, in
   std::lock_guard<std::mutex> g(h->mu);
   AMDR_HIP(hipSetDevice(h->device));
   return run_search(h, 0, Q_dev, nq, k, scores_dev, ids_dev, (hipStream_t)stream);
+}
+
+int amdr_dense_search_fuse_device(amdr_dense_t* h, const float* Q_dev, int32_t nq, int32_t k,
+                                  const amdr_fuse_params_t* p, const int64_t* dense_row2uid, const int64_t* bm25_ids,
+                                  const double* bm25_scores, int32_t kb, const int64_t* bm25_row2uid,
+                                  float* dense_scores_dev, int64_t* dense_ids_dev, int64_t* out_ids, double* out_vals,
+                                  int32_t* out_mask, int32_t* out_count, void* stream) {
+  int rc = check_search_args(h, Q_dev, nq, k, dense_scores_dev, dense_ids_dev);
+  if (rc) return rc;
+  AMDR_REQUIRE(p != nullptr, "dense_search_fuse: null params");
+  AMDR_REQUIRE(p->method >= 0 && p->method <= AMDR_FUSE_WEIGHTED_SUM, "dense_search_fuse: method=%d", p->method);
+  AMDR_REQUIRE(kb >= 0 && kb <= AMDR_MAX_K && (kb == 0 || (bm25_ids && bm25_scores)), "dense_search_fuse: bad BM25 lists");
+  AMDR_REQUIRE(nq == 0 || (out_ids && out_vals && out_mask && out_count), "dense_search_fuse: null output");
+  if (nq == 0) return AMDR_OK;
+  std::lock_guard<std::mutex> g(h->mu);
+  AMDR_HIP(hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  FuseTail tail{p, dense_row2uid, bm25_ids, bm25_scores, kb, bm25_row2uid, out_ids, out_vals, out_mask, out_count};
+  if (!two_level_applies(h, nq, k) && nq >= kBatchedMin && h->n > 0 && dense_mfma_supported(h->d))
+    return run_search_batched(h, 0, Q_dev, nq, k, dense_scores_dev, dense_ids_dev, st, false, &tail);
+  if ((rc = run_search(h, 0, Q_dev, nq, k, dense_scores_dev, dense_ids_dev, st))) return rc;
+  return dense_fuse_plain_launch(tail, 0, nq, k, dense_scores_dev, dense_ids_dev, st);
 }
 
 int amdr_dense_search(amdr_dense_t* h, const float* Q_host, int32_t nq, int32_t k, float* scores_host,

@@ -407,36 +407,6 @@ __global__ __launch_bounds__(WAVES * 64) void scores_slab_topk_kernel(const floa
   }
 }
 
-// Two queries per wave (lanes 0-31 / 32-63), for rows of <= 1024 scores at k <= 32 when there is a
-// single slab — the serving corpora under a long batch.  grid.x = ceil(nq / 2); a wave whose
-// selector reports mass ties (-1) ranks its two rows one after the other with the staged selector.
-template <int V>
-__device__ __forceinline__ int select_row_pair(const float* __restrict__ S, long ldS, long n, int q, bool has_q, int k,
-                                               int lane, C32* scratch, C32& out) {
-  static_assert(V % 4 == 0, "four consecutive scores per 16-byte load");
-  const float* row = S + (size_t)q * ldS;
-  const int j = lane & 31;
-  // 16-byte loads (a half-wave covers 512 B of its row per instruction): the kernel waits on memory
-  // for two thirds of its life, so fewer, wider requests in flight earlier is what shortens it.
-  // Rows are padded to ldS (a multiple of 32 floats), so a whole float4 below ldS is inside the row.
-  v4f blk[V / 4];
-#pragma unroll
-  for (int u = 0; u < V / 4; ++u) {
-    const long c0 = 128L * u + 4 * j;
-    const v4f z = {0.f, 0.f, 0.f, 0.f};
-    blk[u] = (has_q && c0 < ldS) ? __builtin_nontemporal_load(reinterpret_cast<const v4f*>(row + c0)) : z;  // read once
-  }
-  u32 sk[V];  // score keys only; ids (128 u + 4 j + e) are attached to the survivors (wave_select_small_pair32)
-#pragma unroll
-  for (int u = 0; u < V / 4; ++u)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const long r = 128L * u + 4 * j + e;
-      sk[4 * u + e] = (has_q && r < n) ? ord32(blk[u][e]) : 0u;
-    }
-  return wave_select_small_pair32<V>(sk, [&](int v) { return 128 * (v >> 2) + 4 * j + (v & 3); }, k, scratch, lane, out);
-}
-
 __global__ __launch_bounds__(64) void scores_pair_topk_kernel(const float* __restrict__ S, long ldS, long n, int nq,
                                                               int k, int cap, float* __restrict__ fin_scores,
                                                               long long* __restrict__ fin_ids) {
@@ -446,15 +416,7 @@ __global__ __launch_bounds__(64) void scores_pair_topk_kernel(const float* __res
   const int q = 2 * blockIdx.x + (lane >> 5);
   const bool has_q = q < nq;
   C32 out = C32::pad();
-  int got;
-  if (n <= 256)
-    got = select_row_pair<8>(S, ldS, n, q, has_q, k, lane, buf, out);
-  else if (n <= 512)
-    got = select_row_pair<16>(S, ldS, n, q, has_q, k, lane, buf, out);
-  else if (n <= 640)
-    got = select_row_pair<20>(S, ldS, n, q, has_q, k, lane, buf, out);
-  else
-    got = select_row_pair<32>(S, ldS, n, q, has_q, k, lane, buf, out);
+  const int got = select_row_pair_any(S, ldS, n, q, has_q, k, lane, buf, out);
   if (got >= 0) {
     const int j = lane & 31;
     if (has_q && j < k) {

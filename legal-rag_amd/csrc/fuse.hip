@@ -14,6 +14,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -287,11 +288,18 @@ __global__ __launch_bounds__(64) void fuse_kernel(amdr_fuse_params_t P, ChanIn c
 // reductions run inside the W-lane group and the ballots are cut to the group's bits.  The
 // kernel is bound by vector instructions issued per wave (fp64 divisions), not by data, so
 // halving the waves halves its time.
-template <int W>
-__global__ __launch_bounds__(64) void fuse_packed_kernel(amdr_fuse_params_t P, ChanIn c0, ChanIn c1, ChanIn c2, int nq,
-                                                         int max_out, long long* __restrict__ out_ids,
-                                                         double* __restrict__ out_vals, int* __restrict__ out_mask,
-                                                         int* __restrict__ out_count) {
+// Entries a caller already holds in registers (lane sl = list position sl of its query): the fused dense top-k +
+// fusion kernel hands over the dense list straight from its selector and the BM25 list it requested up front.
+struct FusePre {
+  bool have[3];
+  long long id[3];  // raw channel id (-1 = padding), before row2uid
+  double s[3];
+};
+template <int W, bool PRE>
+__device__ __forceinline__ void fuse_packed_body(const amdr_fuse_params_t& P, const ChanIn& c0, const ChanIn& c1,
+                                                 const ChanIn& c2, int nq, int max_out, long long* __restrict__ out_ids,
+                                                 double* __restrict__ out_vals, int* __restrict__ out_mask,
+                                                 int* __restrict__ out_count, const FusePre& pre) {
   constexpr int G = 64 / W;  // queries per wave
   __shared__ long long s_uid[G][W];
   __shared__ double s_sc[G][W];
@@ -325,7 +333,12 @@ __global__ __launch_bounds__(64) void fuse_packed_kernel(amdr_fuse_params_t P, C
     const bool inr = live && j < ch[c].k;
     long long id = -1;
     double s = 0.0;
-    if (inr) {  // id and score are requested together: one memory round trip, not two
+    if (PRE && pre.have[c]) {
+      if (inr) {
+        id = pre.id[c];
+        s = pre.s[c];
+      }
+    } else if (inr) {  // id and score are requested together: one memory round trip, not two
       id = ch[c].ids[(size_t)qi * ch[c].k + j];
       s = chan_score(ch[c], qi, j);
     }
@@ -453,6 +466,83 @@ __global__ __launch_bounds__(64) void fuse_packed_kernel(amdr_fuse_params_t P, C
   if (live && sl == 0) out_count[qi] = kept;
 }
 
+template <int W>
+__global__ __launch_bounds__(64) void fuse_packed_kernel(amdr_fuse_params_t P, ChanIn c0, ChanIn c1, ChanIn c2, int nq,
+                                                         int max_out, long long* __restrict__ out_ids,
+                                                         double* __restrict__ out_vals, int* __restrict__ out_mask,
+                                                         int* __restrict__ out_count) {
+  FusePre none;
+  none.have[0] = none.have[1] = none.have[2] = false;
+  fuse_packed_body<W, false>(P, c0, c1, c2, nq, max_out, out_ids, out_vals, out_mask, out_count, none);
+}
+
+// Dense top-k + fusion in ONE kernel for the serving shape under a batch (dense + BM25, <= 1 024 rows, kd + kb <= 32):
+// two queries per wave, lanes 0-31 / 32-63 — the mapping of scores_pair_topk_kernel AND of fuse_packed_kernel<32>.
+// The half-wave ranks its row of the score matrix S (the same selector, the same bits), writes the dense channel's
+// own (scores, ids) and keeps them in its lanes — lane j = list position j, exactly what the packed fusion wants —
+// while the BM25 list it requested BEFORE the selection arrives.  Against the two launches: no store + reload of
+// the dense list, one memory round trip of the fusion hidden behind the selection, one launch and one wave start
+// fewer per two queries.  Mass ties at the cut (the selector's -1) rank the two rows one after the other with the
+// staged selector, as scores_pair_topk_kernel does, and then fuse from its list.
+__global__ __launch_bounds__(64) void dense_select_fuse_kernel(amdr_fuse_params_t P, const float* __restrict__ S,
+                                                               long ldS, long n, int nq, int kd, int cap,
+                                                               float* __restrict__ fin_scores,
+                                                               long long* __restrict__ fin_ids, ChanIn c0, ChanIn c1,
+                                                               int max_out, long long* __restrict__ out_ids,
+                                                               double* __restrict__ out_vals, int* __restrict__ out_mask,
+                                                               int* __restrict__ out_count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  C32* buf = reinterpret_cast<C32*>(smem);  // cap entries (>= 128): staged-selector list; the pair selector uses 64
+  const int lane = threadIdx.x, sl = lane & 31;
+  const int q = 2 * blockIdx.x + (lane >> 5);
+  const bool has_q = q < nq;
+  FusePre pre;
+  pre.have[0] = pre.have[1] = true;
+  pre.have[2] = false;
+  pre.id[1] = -1;
+  pre.s[1] = 0.0;
+  if (has_q && sl < c1.k) {  // the BM25 list: in flight during the selection
+    pre.id[1] = c1.ids[(size_t)q * c1.k + sl];
+    pre.s[1] = chan_score(c1, q, sl);
+  }
+  C32 out = C32::pad();
+  int got = select_row_pair_any(S, ldS, n, q, has_q, kd, lane, buf, out);
+  if (got < 0) {  // wave-uniform: mass ties at the cut in one of the two rows
+    for (int hh = 0; hh < 2; ++hh) {
+      const int qq = 2 * blockIdx.x + hh;
+      if (qq >= nq) break;
+      const float* row = S + (size_t)qq * ldS;
+      WaveTopK<C32> tk;
+      tk.init(buf, cap, kd);
+      for (long base = 0; base < n; base += 64) {
+        const long r = base + lane;
+        const bool v = r < n;
+        tk.push_lanes(v ? C32::make(row[r], (u32)r) : C32::pad(), v, lane);
+      }
+      tk.finalize(lane);
+      if ((lane >> 5) == hh) {
+        got = tk.cnt;
+        out = sl < tk.cnt ? tk.buf[sl] : C32::pad();
+      }
+      wave_lds_fence();
+    }
+  }
+  const bool v = sl < got;
+  if (has_q && sl < kd) {
+    fin_scores[(size_t)q * kd + sl] = v ? out.score() : -FLT_MAX;
+    fin_ids[(size_t)q * kd + sl] = v ? out.id() : -1ll;
+  }
+  pre.id[0] = v ? out.id() : -1ll;
+  pre.s[0] = v ? (double)out.score() : 0.0;
+  ChanIn none;
+  none.ids = nullptr;
+  none.scores = nullptr;
+  none.row2uid = nullptr;
+  none.k = 0;
+  none.is_f64 = 0;
+  fuse_packed_body<32, true>(P, c0, c1, none, nq, max_out, out_ids, out_vals, out_mask, out_count, pre);
+}
+
 // fuse_kernel for long candidate lists, the packed forms when a query fits in 32 or 16 lanes
 static void launch_fuse(const amdr_fuse_params_t& P, const ChanIn& c0, const ChanIn& c1, const ChanIn& c2, int nq,
                         int max_out, long long* ids, double* vals, int* mask, int* count, hipStream_t st) {
@@ -551,6 +641,38 @@ __global__ __launch_bounds__(64) void rerank_blend_kernel(int max_out, const int
 static size_t rerank_lds(int max_out) {
   return (size_t)max_out * (AMDR_FUSE_NVALS + 2) * sizeof(double) + (size_t)max_out * sizeof(long long) +
          (size_t)max_out * 2 * sizeof(int);
+}
+
+bool dense_select_fuse_applies(long n, int slabs, int m, int kd, int kb) {
+  const char* e = getenv("AMDR_DENSE_FUSE");  // "0" pins the two-launch form (A/B, tests)
+  if (e && e[0] == '0') return false;
+  return slabs == 1 && n >= 1 && n <= 1024 && kd >= 1 && kd <= 32 && kb >= 0 && kd + kb <= 32 && m >= 1;
+}
+
+int dense_select_fuse_launch(const FuseTail& t, int q0, const float* S, long ldS, long n, int m, int kd, int cap,
+                             float* fin_scores, int64_t* fin_ids, hipStream_t st) {
+  const int mo = kd + t.kb;
+  ChanIn c0{nullptr, nullptr, (const long long*)t.dense_row2uid, kd, 0};
+  ChanIn c1{(const long long*)(t.kb ? t.bm25_ids + (size_t)q0 * t.kb : nullptr),
+            t.kb ? (const void*)(t.bm25_scores + (size_t)q0 * t.kb) : nullptr, (const long long*)t.bm25_row2uid, t.kb, 1};
+  hipLaunchKernelGGL(dense_select_fuse_kernel, dim3((m + 1) / 2), dim3(64), (size_t)cap * sizeof(C32), st, *t.p, S, ldS, n,
+                     m, kd, cap, fin_scores, (long long*)fin_ids, c0, c1, mo, (long long*)(t.out_ids + (size_t)q0 * mo),
+                     t.out_vals + (size_t)q0 * mo * AMDR_FUSE_NVALS, t.out_mask + (size_t)q0 * mo, t.out_count + q0);
+  AMDR_HIP(hipGetLastError());
+  return AMDR_OK;
+}
+
+int dense_fuse_plain_launch(const FuseTail& t, int q0, int m, int kd, const float* dense_scores, const int64_t* dense_ids,
+                            hipStream_t st) {
+  const int mo = kd + t.kb;
+  ChanIn c0{(const long long*)dense_ids, dense_scores, (const long long*)t.dense_row2uid, kd, 0};
+  ChanIn c1{(const long long*)(t.kb ? t.bm25_ids + (size_t)q0 * t.kb : nullptr),
+            t.kb ? (const void*)(t.bm25_scores + (size_t)q0 * t.kb) : nullptr, (const long long*)t.bm25_row2uid, t.kb, 1};
+  ChanIn c2{nullptr, nullptr, nullptr, 0, 0};
+  launch_fuse(*t.p, c0, c1, c2, m, mo, (long long*)(t.out_ids + (size_t)q0 * mo),
+              t.out_vals + (size_t)q0 * mo * AMDR_FUSE_NVALS, t.out_mask + (size_t)q0 * mo, t.out_count + q0, st);
+  AMDR_HIP(hipGetLastError());
+  return AMDR_OK;
 }
 
 }  // namespace amdr

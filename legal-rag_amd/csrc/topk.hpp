@@ -489,6 +489,47 @@ __device__ inline int wave_select_small_pair32(const u32 (&sk)[V], IdOf&& id_of,
   return cnt;
 }
 
+typedef float tk_v4f __attribute__((ext_vector_type(4)));
+
+// Two queries per wave (lanes 0-31 / 32-63), for rows of <= 1024 scores at k <= 32 when there is a
+// single slab — the serving corpora under a long batch.  grid.x = ceil(nq / 2); a wave whose
+// selector reports mass ties (-1) ranks its two rows one after the other with the staged selector.
+template <int V>
+__device__ __forceinline__ int select_row_pair(const float* __restrict__ S, long ldS, long n, int q, bool has_q, int k,
+                                               int lane, C32* scratch, C32& out) {
+  static_assert(V % 4 == 0, "four consecutive scores per 16-byte load");
+  const float* row = S + (size_t)q * ldS;
+  const int j = lane & 31;
+  // 16-byte loads (a half-wave covers 512 B of its row per instruction): the kernel waits on memory
+  // for two thirds of its life, so fewer, wider requests in flight earlier is what shortens it.
+  // Rows are padded to ldS (a multiple of 32 floats), so a whole float4 below ldS is inside the row.
+  tk_v4f blk[V / 4];
+#pragma unroll
+  for (int u = 0; u < V / 4; ++u) {
+    const long c0 = 128L * u + 4 * j;
+    const tk_v4f z = {0.f, 0.f, 0.f, 0.f};
+    blk[u] = (has_q && c0 < ldS) ? __builtin_nontemporal_load(reinterpret_cast<const tk_v4f*>(row + c0)) : z;  // read once
+  }
+  u32 sk[V];  // score keys only; ids (128 u + 4 j + e) are attached to the survivors (wave_select_small_pair32)
+#pragma unroll
+  for (int u = 0; u < V / 4; ++u)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long r = 128L * u + 4 * j + e;
+      sk[4 * u + e] = (has_q && r < n) ? ord32(blk[u][e]) : 0u;
+    }
+  return wave_select_small_pair32<V>(sk, [&](int v) { return 128 * (v >> 2) + 4 * j + (v & 3); }, k, scratch, lane, out);
+}
+
+// rows of <= 256 / 512 / 640 / 1024 scores: 8 / 16 / 20 / 32 keys per lane
+__device__ __forceinline__ int select_row_pair_any(const float* __restrict__ S, long ldS, long n, int q, bool has_q,
+                                                   int k, int lane, C32* scratch, C32& out) {
+  if (n <= 256) return select_row_pair<8>(S, ldS, n, q, has_q, k, lane, scratch, out);
+  if (n <= 512) return select_row_pair<16>(S, ldS, n, q, has_q, k, lane, scratch, out);
+  if (n <= 640) return select_row_pair<20>(S, ldS, n, q, has_q, k, lane, scratch, out);
+  return select_row_pair<32>(S, ldS, n, q, has_q, k, lane, scratch, out);
+}
+
 // Merge the finalized lists of all waves of a block into wave 0's list.
 // Call with all threads; contains block barriers.  lists: [nwaves][stride]
 // where each wave's WaveTopK.buf == lists + wave*stride.

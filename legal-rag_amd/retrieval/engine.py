@@ -123,17 +123,35 @@ class HybridEngine:
         b, kb = chan(bm25, self.maps[1])
         c, kc = chan(colbert, self.maps[2])
         mo = kd + kb + kc
+        pk, ids, vals, mask, count = self._fused_outputs(nq, mo)
+        _native.fuse_device(params, nq, d, b, c, ids.data_ptr(), vals.data_ptr(), mask.data_ptr(), count.data_ptr(),
+                            device=self.device, stream=_stream())
+        return BatchResult(ids=ids, vals=vals, mask=mask, count=count, packed=pk)
+
+    def _fused_outputs(self, nq: int, mo: int):
         o1 = nq * mo * 8
         o2 = o1 + nq * mo * _native.FUSE_NVALS * 8
         o3 = o2 + nq * mo * 4
         pk = self._buf("fpk", (o3 + nq * 4,), torch.uint8)  # the four outputs side by side: one D2H serves the host API
-        ids = pk[:o1].view(torch.int64).view(nq, mo)
-        vals = pk[o1:o2].view(torch.float64).view(nq, mo, _native.FUSE_NVALS)
-        mask = pk[o2:o3].view(torch.int32).view(nq, mo)
-        count = pk[o3:].view(torch.int32)
-        _native.fuse_device(params, nq, d, b, c, ids.data_ptr(), vals.data_ptr(), mask.data_ptr(), count.data_ptr(),
-                            device=self.device, stream=_stream())
-        return BatchResult(ids=ids, vals=vals, mask=mask, count=count, packed=pk)
+        return (pk, pk[:o1].view(torch.int64).view(nq, mo), pk[o1:o2].view(torch.float64).view(nq, mo, _native.FUSE_NVALS),
+                pk[o2:o3].view(torch.int32).view(nq, mo), pk[o3:].view(torch.int32))
+
+    def dense_topk_fuse(self, params: _native.FuseParams, q_emb: torch.Tensor, k: int, bm25):
+        """Dense top-k + fusion with the finished BM25 lists as ONE native call (amdr_dense_search_fuse_device: for the
+        serving corpora under a batch one kernel ranks the score rows and fuses).  Same results as dense_topk + fuse."""
+        nq = q_emb.shape[0]
+        assert q_emb.is_cuda and q_emb.dtype == torch.float32 and q_emb.is_contiguous()
+        bs, bi = bm25
+        kb = int(bi.shape[1])
+        s = self._buf("ds", (nq, k), torch.float32)
+        i = self._buf("di", (nq, k), torch.int64)
+        pk, ids, vals, mask, count = self._fused_outputs(nq, k + kb)
+        m0, m1 = self.maps[0], self.maps[1]
+        self.dense.search_fuse_device(params, q_emb.data_ptr(), nq, k,
+                                      (bi.data_ptr(), bs.data_ptr(), kb, m1.data_ptr() if m1 is not None else 0),
+                                      m0.data_ptr() if m0 is not None else 0, s.data_ptr(), i.data_ptr(), ids.data_ptr(),
+                                      vals.data_ptr(), mask.data_ptr(), count.data_ptr(), _stream())
+        return (s, i), BatchResult(ids=ids, vals=vals, mask=mask, count=count, packed=pk)
 
     def rerank_blend(self, res: BatchResult, ce_raw: torch.Tensor, beta: float) -> BatchResult:
         nq, mo = res.ids.shape
@@ -152,6 +170,15 @@ class HybridEngine:
         """dense + bm25 (+ colbert) top-k -> fuse -> min_final filter, all on device."""
         d = b = c = None
         nq = None
+        if (self.dense is not None and q_emb is not None and self.bm25 is not None and q_ptr is not None
+                and not (self.maxsim is not None and q_tok is not None) and self.shard_offset is None):
+            # dense + BM25 on one GPU, the serving hybrid without ColBERT: BM25 first, then the dense channel and the
+            # fusion in one native call
+            b = self.bm25_topk(q_terms, q_ptr, k)
+            d, res = self.dense_topk_fuse(params, q_emb, k, b)
+            res.dense_scores, res.dense_ids = d
+            res.bm25_scores, res.bm25_ids = b
+            return res
         if self.dense is not None and q_emb is not None:
             d = self.dense_topk(q_emb, k)
             nq = q_emb.shape[0]

@@ -806,6 +806,55 @@ def test_fuse_and_rerank_reproduce_the_notebook_known_answers(nat):
     assert abs(vals[0, 0, 0] - 1.11375) < 1e-15 and f"{vals[0, 0, 0]:.2f}" == "1.11"
 
 
+def test_dense_search_fuse_equals_the_two_launches(nat, monkeypatch):
+    """amdr_dense_search_fuse_device == amdr_dense_search_device + amdr_fuse_device(dense, bm25), bit for bit: the
+    one-kernel form (<= 1 024 rows, k + kb <= 32: dense_select_fuse_kernel), the shapes that run the two launches
+    inside the call, mass ties at the selector's cut (its staged fallback), id maps, an odd batch, no BM25 list."""
+    import torch
+    from legal_rag_amd.retrieval.engine import HybridEngine
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(123)
+    params = nat.make_fuse_params(min_final_score=0.2)
+    cases = [(591, 768, 130, 10, 10), (591, 768, 37, 10, 10), (37, 64, 5, 10, 10), (1024, 128, 33, 16, 16), (1, 64, 6, 10, 10),
+             (1300, 64, 40, 10, 10), (591, 64, 257, 20, 20), (20000, 64, 9, 10, 10), (200, 64, 3, 10, 10), (640, 320, 96, 1, 31),
+             (591, 128, 64, 10, 0)]
+    for n, d, nq, k, kb in cases:
+        X, Q = unit_rows(rng, n, d), unit_rows(rng, nq, d)
+        if n == 591 and d == 768:  # mass ties: blocks of identical rows -> more than 32 keys at the cut for some queries
+            X[100:180] = X[100]
+        dense = nat.DenseIndex(X, device=0)
+        eng = HybridEngine(dense, None, None, device=0)
+        q_emb = torch.from_numpy(Q).to(dev)
+        bs = torch.from_numpy(np.sort(rng.random((nq, max(kb, 1))) * 30.0, axis=1)[:, ::-1].copy()).to(dev)
+        bi = torch.from_numpy(np.stack([rng.permutation(max(n, kb + 1))[: max(kb, 1)] for _ in range(nq)]).astype(np.int64)).to(dev)
+        if kb:
+            bi[0, kb - 2:] = -1  # a padded BM25 list
+        maps = (torch.from_numpy(rng.permutation(n + 40)[:n].astype(np.int64)).to(dev),
+                torch.from_numpy(rng.permutation(n + 40).astype(np.int64)).to(dev)) if n == 200 else (None, None)
+        eng.maps = (maps[0], maps[1], None)
+        b = (bs[:, :kb].contiguous(), bi[:, :kb].contiguous()) if kb else None
+        out = {}
+        for flag in ("1", "0", "sep"):
+            if flag == "sep":  # the two C-ABI calls made separately
+                dch = eng.dense_topk(q_emb, k)
+                res = eng.fuse(params, nq, dch, b, None)
+            else:
+                monkeypatch.setenv("AMDR_DENSE_FUSE", flag)
+                if kb:
+                    dch, res = eng.dense_topk_fuse(params, q_emb, k, b)
+                else:
+                    z = torch.zeros((nq, 0), dtype=torch.float64, device=dev), torch.zeros((nq, 0), dtype=torch.int64, device=dev)
+                    dch, res = eng.dense_topk_fuse(params, q_emb, k, z)
+            torch.cuda.synchronize()
+            out[flag] = [t.cpu().numpy().copy() for t in (dch[0], dch[1], res.ids, res.vals, res.mask, res.count)]
+        for flag in ("0", "sep"):
+            for a, e in zip(out["1"], out[flag]):
+                assert a.shape == e.shape and np.array_equal(a, e, equal_nan=True), (n, d, nq, k, kb, flag)
+        es, ei = __import__("oracle.dense", fromlist=["x"]).flatip_topk(X, Q, k)
+        assert np.array_equal(out["1"][1], ei) or n == 591  # (tied rows: any order of the oracle's argsort is not pinned)
+        dense.close()
+
+
 def test_fuse_batched_equals_single(nat):
     rng = np.random.default_rng(9)
     nq, k = 37, 10
