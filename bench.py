@@ -351,6 +351,7 @@ def run_ucc_colbert(torch, local, params, K, steps):
            "colbert_doc_tokens": tokens, "maxsim_gflop_per_query": 2.0 * 32 * 128 * tokens / 1e9,
            "roofline": maxsim_roofline(ms, tokens, R.nq, note="MaxSim channel (scores + top-k launches), HIP events",
                                        plan=R.maxsim.plan_info(R.nq))}
+    out["roofline"]["traffic"] = pmc_traffic("ucc_colbert", out["roofline"]["kernel"].split(" ")[0])
     R.close()
     return out
 
