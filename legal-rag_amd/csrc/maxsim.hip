@@ -210,7 +210,8 @@ __device__ __forceinline__ float ms_finish(const float (&best)[2], int i16, int 
 
 // fp32 token rows -> the [hi | lo] image (one thread per 8 components), scaled by the store's power of two
 __global__ __launch_bounds__(256) void ms_split_store_kernel(const float* __restrict__ D, long n_tokens, float scale,
-                                                             unsigned char* __restrict__ img) {
+                                                             unsigned char* __restrict__ img,
+                                                             unsigned char* __restrict__ img_hi /* [tok][128 x fp16] */) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;  // (token, group of 8 components)
   if (i >= n_tokens * 16) return;
   const long tok = i >> 4;
@@ -224,6 +225,23 @@ __global__ __launch_bounds__(256) void ms_split_store_kernel(const float* __rest
   ms_split(x, scale, hi, lo);
   *reinterpret_cast<ms8h*>(img + tok * 512 + 16 * g) = hi;
   *reinterpret_cast<ms8h*>(img + tok * 512 + 256 + 16 * g) = lo;
+  *reinterpret_cast<ms8h*>(img_hi + tok * 256 + 16 * g) = hi;
+}
+
+// largest token L2 norm of the store, as float bits (error bound of the first pass of the two-pass top-k)
+__global__ __launch_bounds__(256) void ms_tokmax_kernel(const float* __restrict__ D, long n_tokens,
+                                                        unsigned int* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long wv = ((long)blockIdx.x * 256 + threadIdx.x) >> 6, nw = (long)gridDim.x * 4;
+  float m = 0.f;
+  for (long t = wv; t < n_tokens; t += nw) {
+    const float a = D[t * kDim + lane], b = D[t * kDim + 64 + lane];
+    float ss = a * a + b * b;
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) ss += __shfl_xor(ss, sft);
+    m = fmaxf(m, sqrtf(ss));
+  }
+  if (lane == 0) atomicMax(out, __float_as_uint(m));
 }
 
 // largest |component| of the store as float bits (non-negative floats order like unsigned integers; NaN sorts
@@ -569,6 +587,337 @@ __global__ __launch_bounds__(kMsQ * 64) __attribute__((amdgpu_waves_per_eu(4, 4)
   }
 }
 
+// ---- two-pass top-k: a cheap first pass picks the documents worth the full arithmetic ---------------------------
+// `search` needs the k best documents, not every score.  Pass 1 scores every (query, document) with the hi parts only
+// (ONE fp16 MFMA per block instead of three, a 256-byte-per-token image instead of 512: a third of the matrix cycles and
+// half the bytes).  |a_hi . b_hi - a . b| <= (2^-10 + 2^-22) |a| |b| (each fp16 rounding is 2^-11 relative, per
+// component), so a document's first-pass score is within
+//     eps_q = 1.5 * 2^-10 * (sum_i |q_i|) * max_token |d|  (+ the subnormal term)
+// of its full-form score (the 1.5 covers the fp32 accumulation and the full form's own 2e-6).  If T is the k-th best
+// first-pass score, every document that can be among the k best full-form scores — ties at the cut included — has a
+// first-pass score >= T - 2 eps_q (at most k - 1 documents score above the k-th best s_k, hence T <= s_k + eps, and a
+// top-k document has a >= s_k - eps >= T - 2 eps).  Pass 2 re-scores exactly those documents with the full form
+// (the tile function of the one-pass kernels: the same bits) and the final top-k runs on the re-scored values:
+// identical ids and scores by construction, and by test against the one-pass form.  On the UCC-en / Civil-Code-zh
+// stores 11-13 of 591 / 1 260 documents per query pass the cut at k = 10 (about 90 at k = 80).  A query with more than
+// `cap` candidates (mass near-ties) re-scores every document instead (maxsim_overflow_kernel).
+// Pass 1: the ring kernel above with 64-token tiles of the hi-only image (16-KiB stages again, half the barriers per
+// document), 16 MFMAs and 16 ds_read_b128 per tile, no fma in the epilogue.
+__device__ __forceinline__ int ms_hi_off(int row, int slot) { return row * 256 + ((slot ^ (row & 15)) << 4); }
+
+template <int NBUF>
+__global__ __launch_bounds__(kMsQ * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void maxsim_hi_ring_kernel(
+    const unsigned char* __restrict__ img_hi, const long long* __restrict__ doc_ptr, long n_docs, int docs_per_block,
+    const float* __restrict__ Q, int nq, int q_len, float* __restrict__ approx /*[nq, n_docs]*/, float unscale_d) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // [NBUF][64 * 256]
+  constexpr int kStage = 64 * 256;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r32 = lane & 31, h = lane >> 5;
+  const int qi = blockIdx.x * kMsQ + wave;
+  const bool live = qi < nq;
+  const long d0 = (long)blockIdx.y * docs_per_block;
+  long d1 = d0 + docs_per_block;
+  if (d1 > n_docs) d1 = n_docs;
+
+  ms8h qh[8], ql_unused[8];
+  float unscale;
+  ms_load_query_h(Q + (size_t)(live ? qi : 0) * q_len * kDim, q_len, live, r32, h, qh, ql_unused, unscale);
+  unscale *= unscale_d;
+
+  // DMA role: piece u (0, 1) of this wave covers stage bytes [(2 wave + u) * 1024, + 1024) = tile rows 4 (2 wave + u) .. + 3
+  // (256 B each); lane l: row + (l >> 4), PHYSICAL slot l & 15, which holds logical slot ^ (row & 15)
+  long poff[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int prow = 4 * (2 * wave + u) + (lane >> 4);
+    poff[u] = (long)prow * 256 + (((lane & 15) ^ (prow & 15)) << 4);
+  }
+  int foff[8];  // fragment reads: row r32 (+ 32 for the second row block: 32 * 256 B further, same row & 15), chunk 2 s + h
+#pragma unroll
+  for (int st = 0; st < 8; ++st) foff[st] = ms_hi_off(r32, 2 * st + h);
+
+  struct Cur {
+    long doc, t_lo;
+    int len, tok0;
+  };
+  auto advance = [&](Cur& c) {
+    c.tok0 += 64;
+    if (c.tok0 >= c.len) {
+      c.doc += 1;
+      c.tok0 = 0;
+      if (c.doc < d1) {
+        c.t_lo = doc_ptr[c.doc];
+        c.len = (int)(doc_ptr[c.doc + 1] - c.t_lo);
+      }
+    }
+  };
+  auto issue = [&](const Cur& c, int stage) {
+    const unsigned char* src = img_hi + (size_t)(c.t_lo + c.tok0) * 256;  // wave-uniform
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      __builtin_amdgcn_global_load_lds(AMDR_MS_GPTR(src + poff[u]),
+                                       AMDR_MS_LPTR(ring + stage * kStage + (2 * wave + u) * 1024), 16, 0, 0);
+  };
+  Cur prod, cur;
+  prod.doc = d0;
+  prod.t_lo = doc_ptr[d0];
+  prod.len = (int)(doc_ptr[d0 + 1] - prod.t_lo);
+  prod.tok0 = 0;
+  cur = prod;
+  int issued = 0, done = 0;
+#pragma unroll
+  for (int i = 0; i < NBUF - 1; ++i) {
+    if (prod.doc < d1) {
+      issue(prod, issued % NBUF);
+      ++issued;
+      advance(prod);
+    }
+  }
+  float best = -FLT_MAX;
+  while (cur.doc < d1) {
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0); then this wave's pieces of tile `done` (see maxsim_scores_ring_kernel)
+    const int behind = issued - done - 1;
+    if (behind >= 3) {
+      __builtin_amdgcn_s_waitcnt(0x0F76);
+    } else if (behind == 2) {
+      __builtin_amdgcn_s_waitcnt(0x0F74);
+    } else if (behind == 1) {
+      __builtin_amdgcn_s_waitcnt(0x0F72);
+    } else {
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (prod.doc < d1) {
+      issue(prod, issued % NBUF);
+      ++issued;
+      advance(prod);
+    }
+    const unsigned char* tile = ring + (done % NBUF) * kStage;
+    const int remain = cur.len - cur.tok0;
+    ms8h a0[8], a1[8];
+#pragma unroll
+    for (int st = 0; st < 8; ++st) a0[st] = *reinterpret_cast<const ms8h*>(tile + foff[st]);
+    f32x16 c0, c1;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) c0[j] = c1[j] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 8; ++st) c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[st], qh[st], c0, 0, 0, 0);
+    if (remain > 32) {  // wave-uniform: the second 32-token row block holds tokens of this document
+#pragma unroll
+      for (int st = 0; st < 8; ++st) a1[st] = *reinterpret_cast<const ms8h*>(tile + 32 * 256 + foff[st]);
+#pragma unroll
+      for (int st = 0; st < 8; ++st) c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[st], qh[st], c1, 0, 0, 0);
+    }
+    if (remain < 64) {  // last tile of a document: rows >= remain are no tokens of it
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int row = (j & 3) + 8 * (j >> 2) + 4 * h;
+        if (row >= remain) c0[j] = -FLT_MAX;
+        if (32 + row >= remain) c1[j] = -FLT_MAX;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) best = fmaxf(best, fmaxf(c0[j], c1[j]));
+    if (remain <= 64) {
+      const float total = ms_finish_h(best, r32, h, q_len, unscale);
+      if (live && lane == 0) approx[(size_t)qi * n_docs + cur.doc] = total;
+      best = -FLT_MAX;
+    }
+    ++done;
+    advance(cur);
+  }
+}
+
+// Between the passes, one wave per query: T = the k-th best first-pass score, eps from the query's token norms, the
+// list of documents with a first-pass score >= T - 2 eps (ascending ids, at most cap; more -> overflow), and the
+// re-scored row initialised to "not a candidate".
+__global__ __launch_bounds__(64) void maxsim_select_kernel(const float* __restrict__ approx, long n_docs,
+                                                           const float* __restrict__ Q, int q_len, int k, int cap_sel,
+                                                           float d_norm_max, float unscale_d, int cap,
+                                                           float* __restrict__ exact /*[nq, n_docs]*/,
+                                                           int* __restrict__ cand /*[nq, cap]*/, int* __restrict__ cnt,
+                                                           int* __restrict__ overflow) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  C32* buf = reinterpret_cast<C32*>(smem);
+  const int lane = threadIdx.x, q = blockIdx.x;
+  const float* row = approx + (size_t)q * n_docs;
+  WaveTopK<C32> tk;
+  tk.init(buf, cap_sel, k);
+  for (long base = 0; base < n_docs; base += 64) {
+    const long d = base + lane;
+    const bool v = d < n_docs;
+    tk.push_lanes(v ? C32::make(row[d], (u32)d) : C32::pad(), v, lane);
+  }
+  tk.finalize(lane);
+  const float T = tk.cnt >= k ? tk.buf[k - 1].score() : -FLT_MAX;  // fewer than k documents: every one is a candidate
+  wave_lds_fence();
+  // eps: token norms and the query's power-of-two scale, as the scoring kernels take it
+  const float* Qq = Q + (size_t)q * q_len * kDim;
+  float nsum = 0.f, amax = 0.f;
+  for (int i = 0; i < q_len; ++i) {
+    const float a = Qq[i * kDim + lane], b = Qq[i * kDim + 64 + lane];
+    float ss = a * a + b * b;
+    amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b)));
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) ss += __shfl_xor(ss, sft);
+    nsum += sqrtf(ss);
+  }
+#pragma unroll
+  for (int sft = 1; sft < 64; sft <<= 1) amax = fmaxf(amax, __shfl_xor(amax, sft));
+  int e = 0;
+  if (amax > 0.f && amax <= FLT_MAX) (void)frexpf(amax, &e);
+  const float unscale_q = ldexpf(1.f, e);
+  const float eps = 1.5f * 9.765625e-4f * nsum * d_norm_max * 1.0001f +
+                    (float)q_len * 256.f * 2.98023224e-8f * unscale_q * unscale_d;  // + operands in fp16's subnormal range
+  const float thr = (T == -FLT_MAX) ? -FLT_MAX : T - 2.f * eps;
+  int n = 0;
+  for (long base = 0; base < n_docs; base += 64) {
+    const long d = base + lane;
+    const bool v = d < n_docs;
+    const float a = v ? row[d] : 0.f;
+    const bool pass = v && (a >= thr || thr == -FLT_MAX);
+    if (v) exact[(size_t)q * n_docs + d] = -FLT_MAX;
+    const unsigned long long m = __ballot(pass);
+    const int at = n + __popcll(lane ? (m & (~0ull >> (64 - lane))) : 0ull);
+    if (pass && at < cap) cand[(size_t)q * cap + at] = (int)d;
+    n += __popcll(m);
+  }
+  if (lane == 0) {
+    overflow[q] = n > cap ? 1 : 0;
+    cnt[q] = n > cap ? 0 : n;
+  }
+}
+
+// Full-form score of one (query, document) by ONE wave, the document's tiles staged through a wave-private 16-KiB LDS
+// stage by LDS-DMA (16 pieces of 1 KiB per tile: whole 512-byte token rows per request).  The first version
+// fetched the MFMA fragments straight from global memory, as maxsim_scores_h_kernel does for a single query: 16-byte
+// pieces of 32 different rows per load instruction — 15 k candidate pairs per launch then moved ~8x their bytes through
+// the L1s and pass 2 took as long as pass 1 (0.98 ms).  Same tile function, same operands: the same bits.
+__device__ __forceinline__ float ms_exact_doc_lds(const unsigned char* __restrict__ img,
+                                                  const long long* __restrict__ doc_ptr, long doc, const ms8h (&qh)[8],
+                                                  const ms8h (&ql)[8], int lane, int q_len, float unscale,
+                                                  unsigned char* stage /* this wave's 16 KiB */) {
+  const int r32 = lane & 31, h = lane >> 5;
+  const long t_lo = doc_ptr[doc];
+  const int len = (int)(doc_ptr[doc + 1] - t_lo);
+  long poff[16];  // piece u: tile rows 2 u and 2 u + 1; lane: row + (l >> 5), PHYSICAL slot l & 31 <- logical slot ^ (row & 15)
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int prow = 2 * u + (lane >> 5);
+    poff[u] = (long)prow * 512 + (((lane & 31) ^ (prow & 15)) << 4);
+  }
+  int foff[8];
+#pragma unroll
+  for (int st = 0; st < 8; ++st) foff[st] = ms_tile_off(r32, 2 * st + h);
+  float best = -FLT_MAX;
+  for (int tok0 = 0; tok0 < len; tok0 += 32) {
+    const unsigned char* src = img + (size_t)(t_lo + tok0) * 512;
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // the fragment reads of the previous tile are done: the stage may be refilled
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      __builtin_amdgcn_global_load_lds(AMDR_MS_GPTR(src + poff[u]), AMDR_MS_LPTR(stage + u * 1024), 16, 0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the tile has landed (the other waves of the CU cover the wait)
+    asm volatile("" ::: "memory");
+    ms8h ah[8], al[8];
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      const unsigned char* fp = stage + foff[st];
+      ah[st] = *reinterpret_cast<const ms8h*>(fp);
+      al[st] = *reinterpret_cast<const ms8h*>(fp + 256);
+    }
+    ms_tile_h(ah, al, qh, ql, h, len - tok0, best);
+  }
+  return ms_finish_h(best, r32, h, q_len, unscale);
+}
+
+// exclusive prefix sum of the candidate counts: off[q] = first item of query q in the flat work list, off[nq] = items
+__global__ __launch_bounds__(256) void maxsim_offsets_kernel(const int* __restrict__ cnt, int nq, int* __restrict__ off) {
+  __shared__ int part[256];
+  int carry = 0;
+  for (int base = 0; base < nq; base += 256) {
+    const int i = base + threadIdx.x;
+    const int v = i < nq ? cnt[i] : 0;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int sft = 1; sft < 256; sft <<= 1) {
+      const int o = threadIdx.x >= sft ? part[threadIdx.x - sft] : 0;
+      __syncthreads();
+      part[threadIdx.x] += o;
+      __syncthreads();
+    }
+    if (i < nq) off[i] = carry + part[threadIdx.x] - v;
+    carry += part[255];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) off[nq] = carry;
+}
+
+// Pass 2: the candidate (query, document) pairs as ONE flat work list cut into equal contiguous shares, one per wave of
+// a grid that just fills the chip (a grid of (slot, query) blocks was mostly empty blocks queueing for LDS: 0.76 ms for
+// 15 k pairs).  A share's items mostly belong to one query: its fragments are loaded once per query change.
+__global__ __launch_bounds__(256) void maxsim_rescore_kernel(const unsigned char* __restrict__ img,
+                                                             const long long* __restrict__ doc_ptr, long n_docs,
+                                                             const float* __restrict__ Q, int nq, int q_len,
+                                                             float unscale_d, const int* __restrict__ cand,
+                                                             const int* __restrict__ off, int cap,
+                                                             float* __restrict__ exact) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char stages[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int total = off[nq];
+  const int G = gridDim.x * kMsWaves, g = blockIdx.x * kMsWaves + wave;
+  const int share = (total + G - 1) / G;
+  const int lo = g * share;
+  int hi = lo + share;
+  if (hi > total) hi = total;
+  if (lo >= hi) return;  // whole wave
+  int q = 0;
+  {  // the query of item lo: the last q with off[q] <= lo
+    int a = 0, b = nq;
+    while (b - a > 1) {
+      const int m = (a + b) >> 1;
+      if (off[m] <= lo) a = m; else b = m;
+    }
+    q = a;
+  }
+  ms8h qh[8], ql[8];
+  float unscale = 1.f;
+  int q_loaded = -1;
+  for (int item = lo; item < hi; ++item) {
+    while (item >= off[q + 1]) ++q;  // queries without candidates are skipped
+    if (q != q_loaded) {
+      ms_load_query_h(Q + (size_t)q * q_len * kDim, q_len, true, lane & 31, lane >> 5, qh, ql, unscale);
+      unscale *= unscale_d;
+      q_loaded = q;
+    }
+    const long doc = cand[(size_t)q * cap + (item - off[q])];
+    const float total_s = ms_exact_doc_lds(img, doc_ptr, doc, qh, ql, lane, q_len, unscale, stages + wave * 16384);
+    if (lane == 0) exact[(size_t)q * n_docs + doc] = total_s;
+  }
+}
+
+// a query whose candidate list overflowed: every document, full form (rare: mass near-ties at the cut)
+__global__ __launch_bounds__(256) void maxsim_overflow_kernel(const unsigned char* __restrict__ img,
+                                                              const long long* __restrict__ doc_ptr, long n_docs,
+                                                              const float* __restrict__ Q, int q_len, float unscale_d,
+                                                              const int* __restrict__ overflow, float* __restrict__ exact) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char stages[];
+  const int q = blockIdx.x;
+  if (!overflow[q]) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  ms8h qh[8], ql[8];
+  float unscale;
+  ms_load_query_h(Q + (size_t)q * q_len * kDim, q_len, true, lane & 31, lane >> 5, qh, ql, unscale);
+  for (long doc = wave; doc < n_docs; doc += kMsWaves) {
+    const float total = ms_exact_doc_lds(img, doc_ptr, doc, qh, ql, lane, q_len, unscale * unscale_d, stages + wave * 16384);
+    if (lane == 0) exact[(size_t)q * n_docs + doc] = total;
+  }
+}
+
 // Per-query top-k over a dense fp32 score row (one block per query).
 __global__ __launch_bounds__(256) void rowscores_topk_kernel(const float* __restrict__ scores, long n, int k, int cap,
                                                               float* __restrict__ out_scores,
@@ -608,7 +957,9 @@ struct amdr_maxsim {
   int64_t n_docs = 0, n_tokens = 0;
   float* D = nullptr;
   unsigned char* img = nullptr;  // [hi 128 x fp16 | lo 128 x fp16] per token, scaled by d_scale (split-fp16 form)
+  unsigned char* img_hi = nullptr;  // [hi 128 x fp16] per token: first pass of the two-pass top-k
   float d_scale = 1.f;           // power of two; img == nullptr: the store is not finite -> fp32-input form only
+  float d_norm_max = 0.f;        // largest token L2 norm (error bound of the first pass)
   long long* doc_ptr = nullptr;
   hipStream_t stream = nullptr;
   std::mutex mu;
@@ -617,13 +968,67 @@ struct amdr_maxsim {
 
 namespace {
 
+bool ms_half(const amdr_maxsim* h) {
+  const char* pin = getenv("AMDR_MAXSIM_F16X3");
+  return h->img != nullptr && !(pin && pin[0] == '0');  // split-fp16 MFMA form (default) / fp32-input form
+}
+// the two-pass top-k: batches on the split-fp16 form, k small against the corpus (AMDR_MAXSIM_TWOPASS=0 pins one pass)
+bool ms_two_pass(const amdr_maxsim* h, int nq, int k, bool want_topk) {
+  const char* pin = getenv("AMDR_MAXSIM_TWOPASS");
+  if (pin && pin[0] == '0') return false;
+  return want_topk && ms_half(h) && nq >= kMsQ && h->img_hi != nullptr && (int64_t)4 * k <= h->n_docs;
+}
+int ms_cand_cap(int k) {
+  const int c = next_pow2(2 * k);
+  return c < 64 ? 64 : c;
+}
+// workspace of one call: the score rows [nq, n_docs]; two-pass: the first-pass rows, the re-scored rows, the candidate lists
+size_t ms_workspace_bytes(const amdr_maxsim* h, int nq, int k, bool want_topk) {
+  const size_t rows = ((size_t)nq * h->n_docs * sizeof(float) + 255) / 256 * 256;
+  if (!ms_two_pass(h, nq, k, want_topk)) return rows;
+  return 2 * rows + ((size_t)nq * ms_cand_cap(k) + 3 * (size_t)nq + 1) * sizeof(int) + 256;
+}
+
 int ms_run(amdr_maxsim* h, const float* Q_dev, int nq, int q_len, int k, float* full_dev, float* scores_dev,
            int64_t* ids_dev, hipStream_t st) {
-  const char* pin = getenv("AMDR_MAXSIM_F16X3");
-  const bool half = h->img != nullptr && !(pin && pin[0] == '0');  // split-fp16 MFMA form (default) / fp32-input form
+  const bool half = ms_half(h);
   const float unscale_d = 1.f / h->d_scale;
   const bool batch = nq >= kMsQ;  // batches: document tiles shared by 8 queries through LDS
-  if (batch && half) {
+  if (ms_two_pass(h, nq, k, scores_dev != nullptr)) {
+    const size_t rows = ((size_t)nq * h->n_docs * sizeof(float) + 255) / 256 * 256;
+    unsigned char* wsb = reinterpret_cast<unsigned char*>(full_dev);
+    float* approx = full_dev;
+    float* exact = reinterpret_cast<float*>(wsb + rows);
+    const int cap = ms_cand_cap(k);
+    int* cand = reinterpret_cast<int*>(wsb + 2 * rows);
+    int* cnt = cand + (size_t)nq * cap;
+    int* ovf = cnt + nq;
+    const char* dpb = getenv("AMDR_MAXSIM_DOCS");  // documents per block of pass 1 (measured: 32 / 48 / 64 within noise, 16 slower)
+    long docs = dpb && atoi(dpb) > 0 ? atoi(dpb) : 32;
+    while (ceil_div(h->n_docs, docs) > 65535) docs *= 2;
+    AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_hi_ring_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 4 * 16384));
+    hipLaunchKernelGGL((maxsim_hi_ring_kernel<4>), dim3(ceil_div(nq, kMsQ), ceil_div(h->n_docs, docs)), dim3(kMsQ * 64),
+                       4 * 16384, st, h->img_hi, h->doc_ptr, (long)h->n_docs, (int)docs, Q_dev, nq, q_len, approx,
+                       unscale_d);
+    const int cap_sel = topk_cap(k);
+    hipLaunchKernelGGL(maxsim_select_kernel, dim3(nq), dim3(64), (size_t)cap_sel * sizeof(C32), st, approx,
+                       (long)h->n_docs, Q_dev, q_len, k, cap_sel, h->d_norm_max, unscale_d, cap, exact, cand, cnt, ovf);
+    constexpr int kPairLds = kMsWaves * 16384;
+    AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_rescore_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds));
+    AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_overflow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds));
+    int* off = ovf + nq;
+    hipLaunchKernelGGL(maxsim_offsets_kernel, dim3(1), dim3(256), 0, st, cnt, nq, off);
+    int dev = 0, cus = 256;
+    AMDR_HIP(hipGetDevice(&dev));
+    AMDR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    hipLaunchKernelGGL(maxsim_rescore_kernel, dim3(2 * cus), dim3(256), kPairLds, st, h->img, h->doc_ptr, (long)h->n_docs,
+                       Q_dev, nq, q_len, unscale_d, cand, off, cap, exact);
+    hipLaunchKernelGGL(maxsim_overflow_kernel, dim3(nq), dim3(256), kPairLds, st, h->img, h->doc_ptr, (long)h->n_docs,
+                       Q_dev, q_len, unscale_d, ovf, exact);
+    AMDR_HIP(hipGetLastError());
+    full_dev = exact;  // the final top-k ranks the re-scored rows
+  } else if (batch && half) {
     const char* rg = getenv("AMDR_MAXSIM_RING");  // LDS stages (2 / 3 / 4 / 6; measured best: 4)
     const int nbuf = rg ? atoi(rg) : 4;
     const char* dpb = getenv("AMDR_MAXSIM_DOCS");  // documents per block (measured best: 16)
@@ -727,11 +1132,21 @@ int amdr_maxsim_create(const float* D_host, const int64_t* doc_ptr, int64_t n_do
     h->d_scale = ldexpf(1.f, -ex);
     e = hipMalloc((void**)&h->img, (size_t)(nt + 32) * 512);  // + one tile: the last tile of the last document reads on
     if (e == hipSuccess) e = hipMemset(h->img + (size_t)nt * 512, 0, (size_t)32 * 512);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->img_hi, (size_t)(nt + 64) * 256);  // + one 64-token tile
+    if (e == hipSuccess) e = hipMemset(h->img_hi + (size_t)nt * 256, 0, (size_t)64 * 256);
+    unsigned int* nm = nullptr;
+    unsigned int nbits = 0;
+    if (e == hipSuccess) e = hipMalloc((void**)&nm, sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMemset(nm, 0, sizeof(unsigned int));
     if (e == hipSuccess) {
       hipLaunchKernelGGL(ms_split_store_kernel, dim3(ceil_div(nt * 16, 256)), dim3(256), 0, 0, h->D, (long)nt, h->d_scale,
-                         h->img);
-      e = hipDeviceSynchronize();
+                         h->img, h->img_hi);
+      hipLaunchKernelGGL(ms_tokmax_kernel, dim3(1024), dim3(256), 0, 0, h->D, (long)nt, nm);
+      e = hipMemcpy(&nbits, nm, sizeof(unsigned int), hipMemcpyDeviceToHost);
+      memcpy(&h->d_norm_max, &nbits, sizeof(float));
     }
+    if (nm) (void)hipFree(nm);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
   }
   if (e != hipSuccess) {
     amdr_maxsim_destroy(h);
@@ -753,7 +1168,12 @@ int amdr_maxsim_plan_info(const amdr_maxsim_t* h, int32_t nq, char* buf, int32_t
   const char* pin = getenv("AMDR_MAXSIM_F16X3");
   const bool half = h->img != nullptr && !(pin && pin[0] == '0');
   const bool batch = nq >= kMsQ;
-  if (half)
+  if (half && batch && h->img_hi && !(getenv("AMDR_MAXSIM_TWOPASS") && getenv("AMDR_MAXSIM_TWOPASS")[0] == '0'))
+    snprintf(buf, buf_len,
+             "maxsim_hi_ring_kernel split-fp16 two-pass top-k (k <= n_docs / 4): pass 1 hi parts only (1 x "
+             "v_mfma_f32_32x32x16_f16 per block) + maxsim_select_kernel + maxsim_rescore_kernel (hi + lo/2048, 3 MFMAs per "
+             "block, candidates only) + rowscores_topk_kernel; full score rows: maxsim_scores_ring_kernel");
+  else if (half)
     snprintf(buf, buf_len, "%s split-fp16 (hi + lo/2048, 3 x v_mfma_f32_32x32x16_f16 per block) + rowscores_topk_kernel",
              batch ? "maxsim_scores_ring_kernel" : "maxsim_scores_h_kernel");
   else
@@ -767,7 +1187,14 @@ int amdr_maxsim_reserve(amdr_maxsim_t* h, int32_t nq_max, int32_t k_max) {
   AMDR_REQUIRE(nq_max >= 1 && k_max >= 1 && k_max <= AMDR_MAX_K, "maxsim_reserve: bad sizes");
   std::lock_guard<std::mutex> g(h->mu);
   AMDR_HIP(hipSetDevice(h->device));
-  int rc = h->full[0].ensure((size_t)nq_max * h->n_docs * sizeof(float));
+  // every call within (nq_max, k_max): the one-pass rows, or the two-pass layout at the largest candidate capacity
+  size_t need = ms_workspace_bytes(h, nq_max, k_max, true);
+  if (ms_half(h) && h->img_hi) {
+    const size_t rows = ((size_t)nq_max * h->n_docs * sizeof(float) + 255) / 256 * 256;
+    const size_t two = 2 * rows + ((size_t)nq_max * ms_cand_cap(k_max) + 3 * (size_t)nq_max + 1) * sizeof(int) + 256;
+    need = two > need ? two : need;
+  }
+  int rc = h->full[0].ensure(need);
   if (!rc) rc = h->qbuf.ensure((size_t)nq_max * AMDR_MAXSIM_QLEN * kDim * sizeof(float));
   if (!rc) rc = h->sbuf.ensure((size_t)nq_max * k_max * sizeof(float));
   if (!rc) rc = h->ibuf.ensure((size_t)nq_max * k_max * sizeof(int64_t));
@@ -782,7 +1209,7 @@ int amdr_maxsim_search_device(amdr_maxsim_t* h, const float* Q_dev, int32_t nq, 
   if (nq == 0) return AMDR_OK;
   std::lock_guard<std::mutex> g(h->mu);
   AMDR_HIP(hipSetDevice(h->device));
-  if ((rc = h->full[0].ensure((size_t)nq * h->n_docs * sizeof(float)))) return rc;
+  if ((rc = h->full[0].ensure(ms_workspace_bytes(h, nq, k, true)))) return rc;
   return ms_run(h, Q_dev, nq, q_len, k, h->full[0].as<float>(), scores_dev, ids_dev, (hipStream_t)stream);
 }
 
@@ -796,7 +1223,7 @@ int amdr_maxsim_search(amdr_maxsim_t* h, const float* Q_host, int32_t nq, int32_
   AMDR_HIP(hipSetDevice(h->device));
   size_t qbytes = (size_t)nq * q_len * kDim * sizeof(float);
   if ((rc = h->qbuf.ensure(qbytes))) return rc;
-  if ((rc = h->full[1].ensure((size_t)nq * h->n_docs * sizeof(float)))) return rc;
+  if ((rc = h->full[1].ensure(ms_workspace_bytes(h, nq, k, true)))) return rc;
   if ((rc = h->sbuf.ensure((size_t)nq * k * sizeof(float)))) return rc;
   if ((rc = h->ibuf.ensure((size_t)nq * k * sizeof(int64_t)))) return rc;
   AMDR_HIP(hipMemcpyAsync(h->qbuf.p, Q_host, qbytes, hipMemcpyHostToDevice, h->stream));
@@ -837,6 +1264,7 @@ int amdr_maxsim_destroy(amdr_maxsim_t* h) {
   }
   if (h->D) (void)hipFree(h->D);
   if (h->img) (void)hipFree(h->img);
+  if (h->img_hi) (void)hipFree(h->img_hi);
   if (h->doc_ptr) (void)hipFree(h->doc_ptr);
   h->full[0].release();
   h->full[1].release();

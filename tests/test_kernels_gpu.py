@@ -657,6 +657,62 @@ def test_maxsim_split_fp16_form_accuracy_scaling_and_pin(nat, monkeypatch):
     assert np.max(np.abs(got[:, ok] - ref[:8, ok])) <= 2e-5 and not np.isfinite(got[:, bad]).all()
 
 
+def test_maxsim_two_pass_topk_equals_one_pass(nat, monkeypatch):
+    """Batched `search` on the split-fp16 form first scores every document with the hi parts only, then re-scores with
+    the full form the documents whose first-pass score is within the proven bound of the k-th best (csrc/maxsim.hip,
+    "two-pass top-k"); AMDR_MAXSIM_TWOPASS=0 pins the one-pass form.  Same ids and the same score BITS — ragged
+    documents, several k, a corpus of near-duplicates (candidate list overflow -> every document re-scored), exact
+    duplicates across the cut (ties -> lower id), fewer documents than 4 k (one pass inside), wide token norms."""
+    from oracle import maxsim as OM
+    rng = np.random.default_rng(2026)
+
+    def run(D, doc_ptr, Q, k):
+        out = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("AMDR_MAXSIM_TWOPASS", flag)
+            idx = nat.MaxSimIndex(D, doc_ptr)
+            out[flag] = idx.search(Q, k)
+            idx.close()
+        assert np.array_equal(out["1"][1], out["0"][1]), k
+        assert np.array_equal(out["1"][0], out["0"][0]), k
+        return out["1"]
+
+    for n_docs, nq, q_len, ks in ((591, 24, 32, (1, 10, 80)), (130, 9, 17, (5, 32)), (1300, 16, 32, (10,)), (50, 8, 32, (10, 13))):
+        lens = rng.integers(1, 221, size=n_docs)
+        lens[:4] = [1, 63, 64, 65]
+        doc_ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        D = unit_rows(rng, int(doc_ptr[-1]), 128)
+        Q = unit_rows(rng, nq * q_len, 128).reshape(nq, q_len, 128)
+        for k in ks:
+            s, i = run(D, doc_ptr, Q, k)
+            ref = OM.maxsim_scores(Q, D, doc_ptr)
+            kk = min(k, n_docs)
+            for b in range(nq):
+                assert np.max(np.abs(s[b, :kk] - ref[b, i[b, :kk]])) <= 1e-5
+                assert np.all(ref[b, i[b, :kk]] >= np.sort(ref[b])[::-1][kk - 1] - 1e-5)
+    # near-duplicates: 200 of 300 documents differ in the 4th decimal -> far more than `cap` candidates -> overflow path;
+    # exact duplicates straddling the cut -> lower id first, in both forms
+    base = unit_rows(rng, 40, 128)
+    docs = [base + 1e-4 * rng.standard_normal(base.shape).astype(np.float32) for _ in range(200)]
+    docs += [unit_rows(rng, int(rng.integers(5, 80)), 128) for _ in range(100)]
+    docs[7] = docs[3].copy()
+    docs[150] = docs[3].copy()
+    D = np.concatenate(docs).astype(np.float32)
+    D /= np.linalg.norm(D, axis=1, keepdims=True)
+    doc_ptr = np.concatenate([[0], np.cumsum([len(x) for x in docs])]).astype(np.int64)
+    Q = np.stack([np.concatenate([base[:20] + 0.05 * rng.standard_normal((20, 128)).astype(np.float32),
+                                  unit_rows(rng, 12, 128)]) for _ in range(8)]).astype(np.float32)
+    Q /= np.linalg.norm(Q, axis=2, keepdims=True)
+    s, i = run(D, doc_ptr, Q, 10)
+    for b in range(8):
+        pos = {int(d): j for j, d in enumerate(i[b])}
+        if 3 in pos and 7 in pos and 150 in pos:
+            assert pos[3] < pos[7] < pos[150] and s[b, pos[3]] == s[b, pos[7]] == s[b, pos[150]]
+    # token norms over three orders of magnitude, a scaled store and tiny queries: the bound follows the norms
+    w = np.exp2(-rng.integers(0, 10, size=D.shape[0])).astype(np.float32)[:, None]
+    run((D * w * np.float32(12.5)).astype(np.float32), doc_ptr, (Q * np.float32(3e-3)).astype(np.float32), 10)
+
+
 def test_maxsim_fuzz_vs_oracle(nat):
     """Seeded sweep of both MaxSim forms (per-pair for < 8 queries, blocked otherwise): ragged
     document lengths around the 32-token tile, document counts around the 8-document group,
