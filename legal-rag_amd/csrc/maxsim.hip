@@ -731,6 +731,144 @@ __global__ __launch_bounds__(kMsQ * 64) __attribute__((amdgpu_waves_per_eu(4, 4)
   }
 }
 
+// Pass 1, two queries per wave.  PMC / arithmetic on the kernel above: a wave reads the whole 16-KiB tile from LDS for 16
+// MFMAs of 32 cycles — 16 waves per CU x 16 KiB per 2 048 pipe cycles = 125 B per clock, the LDS's whole bandwidth: it
+// ran at half its matrix floor (1.0 ms against 0.52).  Here a wave keeps the hi fragments of TWO queries (64 VGPRs) and
+// feeds both from one read of the tile: half the LDS bytes per MFMA.  A block = 4 waves = 8 queries (the tile is shared
+// by as many queries as before), 3 stages = 48 KiB, three blocks per CU.
+constexpr int kMsQ2 = 4;  // waves per block; 2 queries each
+
+template <int NBUF>
+__global__ __launch_bounds__(kMsQ2 * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void maxsim_hi2_ring_kernel(
+    const unsigned char* __restrict__ img_hi, const long long* __restrict__ doc_ptr, long n_docs, int docs_per_block,
+    const float* __restrict__ Q, int nq, int q_len, float* __restrict__ approx /*[nq, n_docs]*/, float unscale_d) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // [NBUF][64 * 256]
+  constexpr int kStage = 64 * 256;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r32 = lane & 31, h = lane >> 5;
+  const int qa = (blockIdx.x * kMsQ2 + wave) * 2, qb = qa + 1;
+  const bool live_a = qa < nq, live_b = qb < nq;
+  const long d0 = (long)blockIdx.y * docs_per_block;
+  long d1 = d0 + docs_per_block;
+  if (d1 > n_docs) d1 = n_docs;
+
+  ms8h qha[8], qhb[8], lo_unused[8];
+  float unscale_a, unscale_b;
+  ms_load_query_h(Q + (size_t)(live_a ? qa : 0) * q_len * kDim, q_len, live_a, r32, h, qha, lo_unused, unscale_a);
+  ms_load_query_h(Q + (size_t)(live_b ? qb : 0) * q_len * kDim, q_len, live_b, r32, h, qhb, lo_unused, unscale_b);
+  unscale_a *= unscale_d;
+  unscale_b *= unscale_d;
+
+  // DMA role: pieces 4 wave .. 4 wave + 3 of the tile's 16 (1 KiB = 4 rows of 256 B each); lane l: row + (l >> 4),
+  // PHYSICAL slot l & 15, which holds logical slot ^ (row & 15)
+  long poff[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int prow = 4 * (4 * wave + u) + (lane >> 4);
+    poff[u] = (long)prow * 256 + (((lane & 15) ^ (prow & 15)) << 4);
+  }
+  int foff[8];
+#pragma unroll
+  for (int st = 0; st < 8; ++st) foff[st] = ms_hi_off(r32, 2 * st + h);
+
+  struct Cur {
+    long doc, t_lo;
+    int len, tok0;
+  };
+  auto advance = [&](Cur& c) {
+    c.tok0 += 64;
+    if (c.tok0 >= c.len) {
+      c.doc += 1;
+      c.tok0 = 0;
+      if (c.doc < d1) {
+        c.t_lo = doc_ptr[c.doc];
+        c.len = (int)(doc_ptr[c.doc + 1] - c.t_lo);
+      }
+    }
+  };
+  auto issue = [&](const Cur& c, int stage) {
+    const unsigned char* src = img_hi + (size_t)(c.t_lo + c.tok0) * 256;  // wave-uniform
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      __builtin_amdgcn_global_load_lds(AMDR_MS_GPTR(src + poff[u]),
+                                       AMDR_MS_LPTR(ring + stage * kStage + (4 * wave + u) * 1024), 16, 0, 0);
+  };
+  Cur prod, cur;
+  prod.doc = d0;
+  prod.t_lo = doc_ptr[d0];
+  prod.len = (int)(doc_ptr[d0 + 1] - prod.t_lo);
+  prod.tok0 = 0;
+  cur = prod;
+  int issued = 0, done = 0;
+#pragma unroll
+  for (int i = 0; i < NBUF - 1; ++i) {
+    if (prod.doc < d1) {
+      issue(prod, issued % NBUF);
+      ++issued;
+      advance(prod);
+    }
+  }
+  float best_a = -FLT_MAX, best_b = -FLT_MAX;
+  while (cur.doc < d1) {
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0); then this wave's 4 pieces of tile `done` (4 loads per tile in flight behind it)
+    const int behind = issued - done - 1;
+    if (behind >= 2) {
+      __builtin_amdgcn_s_waitcnt(0x0F78);  // vmcnt(8)
+    } else if (behind == 1) {
+      __builtin_amdgcn_s_waitcnt(0x0F74);  // vmcnt(4)
+    } else {
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (prod.doc < d1) {
+      issue(prod, issued % NBUF);
+      ++issued;
+      advance(prod);
+    }
+    const unsigned char* tile = ring + (done % NBUF) * kStage;
+    const int remain = cur.len - cur.tok0;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      if (blk == 1 && remain <= 32) break;  // wave-uniform: the second 32-token row block holds no token of this document
+      ms8h a[8];
+#pragma unroll
+      for (int st = 0; st < 8; ++st) a[st] = *reinterpret_cast<const ms8h*>(tile + blk * (32 * 256) + foff[st]);
+      f32x16 ca, cb;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) ca[j] = cb[j] = 0.f;
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        ca = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[st], qha[st], ca, 0, 0, 0);
+        cb = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[st], qhb[st], cb, 0, 0, 0);
+      }
+      if (remain < 32 * (blk + 1)) {  // last row block of a document: rows >= remain are no tokens of it
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (32 * blk + (j & 3) + 8 * (j >> 2) + 4 * h >= remain) ca[j] = cb[j] = -FLT_MAX;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; j += 2) {
+        best_a = fmaxf(best_a, fmaxf(ca[j], ca[j + 1]));
+        best_b = fmaxf(best_b, fmaxf(cb[j], cb[j + 1]));
+      }
+    }
+    if (remain <= 64) {
+      const float ta = ms_finish_h(best_a, r32, h, q_len, unscale_a);
+      const float tb = ms_finish_h(best_b, r32, h, q_len, unscale_b);
+      if (lane == 0) {
+        if (live_a) approx[(size_t)qa * n_docs + cur.doc] = ta;
+        if (live_b) approx[(size_t)qb * n_docs + cur.doc] = tb;
+      }
+      best_a = best_b = -FLT_MAX;
+    }
+    ++done;
+    advance(cur);
+  }
+}
+
 // Between the passes, one wave per query: T = the k-th best first-pass score, eps from the query's token norms, the
 // list of documents with a first-pass score >= T - 2 eps (ascending ids, at most cap; more -> overflow), and the
 // re-scored row initialised to "not a candidate".
@@ -1003,14 +1141,23 @@ int ms_run(amdr_maxsim* h, const float* Q_dev, int nq, int q_len, int k, float* 
     int* cand = reinterpret_cast<int*>(wsb + 2 * rows);
     int* cnt = cand + (size_t)nq * cap;
     int* ovf = cnt + nq;
-    const char* dpb = getenv("AMDR_MAXSIM_DOCS");  // documents per block of pass 1 (measured: 32 / 48 / 64 within noise, 16 slower)
-    long docs = dpb && atoi(dpb) > 0 ? atoi(dpb) : 32;
+    const char* dpb = getenv("AMDR_MAXSIM_DOCS");  // documents per block of pass 1 (UCC-en 16 / 32 / 64 / 128: 1.05 / 1.07 / 1.11 /
+    long docs = dpb && atoi(dpb) > 0 ? atoi(dpb) : 64;  // 1.10 ms; Civil-Code-zh 32 / 64 / 128: 1.48 / 1.28 / 1.28 ms)
     while (ceil_div(h->n_docs, docs) > 65535) docs *= 2;
-    AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_hi_ring_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 4 * 16384));
-    hipLaunchKernelGGL((maxsim_hi_ring_kernel<4>), dim3(ceil_div(nq, kMsQ), ceil_div(h->n_docs, docs)), dim3(kMsQ * 64),
-                       4 * 16384, st, h->img_hi, h->doc_ptr, (long)h->n_docs, (int)docs, Q_dev, nq, q_len, approx,
-                       unscale_d);
+    const char* h2 = getenv("AMDR_MAXSIM_HI2");  // "0": one query per wave (A/B)
+    if (h2 && h2[0] == '0') {
+      AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_hi_ring_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   4 * 16384));
+      hipLaunchKernelGGL((maxsim_hi_ring_kernel<4>), dim3(ceil_div(nq, kMsQ), ceil_div(h->n_docs, docs)), dim3(kMsQ * 64),
+                         4 * 16384, st, h->img_hi, h->doc_ptr, (long)h->n_docs, (int)docs, Q_dev, nq, q_len, approx,
+                         unscale_d);
+    } else {
+      AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_hi2_ring_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   3 * 16384));
+      hipLaunchKernelGGL((maxsim_hi2_ring_kernel<3>), dim3(ceil_div(nq, 2 * kMsQ2), ceil_div(h->n_docs, docs)),
+                         dim3(kMsQ2 * 64), 3 * 16384, st, h->img_hi, h->doc_ptr, (long)h->n_docs, (int)docs, Q_dev, nq,
+                         q_len, approx, unscale_d);
+    }
     const int cap_sel = topk_cap(k);
     hipLaunchKernelGGL(maxsim_select_kernel, dim3(nq), dim3(64), (size_t)cap_sel * sizeof(C32), st, approx,
                        (long)h->n_docs, Q_dev, q_len, k, cap_sel, h->d_norm_max, unscale_d, cap, exact, cand, cnt, ovf);

@@ -33,12 +33,13 @@ for lang in sys.argv[1:] or ["en"]:
     for var in variants:
         flag, ring, docs = var[:3]
         os.environ["AMDR_MAXSIM_TWOPASS"] = var[3] if len(var) > 3 else "1"
+        os.environ["AMDR_MAXSIM_HI2"] = var[4] if len(var) > 4 else "1"
         os.environ["AMDR_MAXSIM_F16X3"] = flag
         os.environ["AMDR_MAXSIM_RING"] = ring
         os.environ["AMDR_MAXSIM_DOCS"] = docs
         ms = bench.event_ms(torch, lambda: idx.search_device(Q.data_ptr(), nq, 32, K, s.data_ptr(), i.data_ptr(), st), 5)
         got = idx.scores(W["Qtok"][:48])
         tf = 2.0 * 32 * 128 * tokens * nq / (ms * 1e-3) / 1e12
-        print(f"{lang} F16X3={flag} ring={ring} docs/block={docs} twopass={os.environ['AMDR_MAXSIM_TWOPASS']}: {ms:.3f} ms per {nq} queries  {nq / ms * 1e3:,.0f} q/s  {tf:.1f} TFLOP/s-equivalent  "
+        print(f"{lang} F16X3={flag} ring={ring} docs/block={docs} twopass={os.environ['AMDR_MAXSIM_TWOPASS']} hi2={os.environ['AMDR_MAXSIM_HI2']}: {ms:.3f} ms per {nq} queries  {nq / ms * 1e3:,.0f} q/s  {tf:.1f} TFLOP/s-equivalent  "
               f"max|err| vs fp64 {np.max(np.abs(got - ref)):.2e}", flush=True)
     idx.close()
