@@ -1,7 +1,7 @@
 # SQ counters of the MaxSim launch (rocprofv3, separate --pmc passes, kernel trace only)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-export AB_VARIANTS="${AB_VARIANTS:-1:4:32}"
+export AB_VARIANTS="${AB_VARIANTS:-1:4:32:0}"  # one-pass form (the counters of profiles/r03_pmc.md §2)
 O=$R/gpurun_out/r3/ms_pmc
 mkdir -p $O
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $O/p1 --output-format csv -- python3 $R/scripts/ab_maxsim.py en > $O/p1.log 2>&1
