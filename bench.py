@@ -626,6 +626,20 @@ def run_hbm_scan(torch, device, n, d, batches, steps, warmup, k=10):
     return out
 
 
+def scan_algorithmic_bytes(plan, n, d, B, k):
+    """(kernel, fp16-first-pass?, queries per scan launch, algorithmic bytes of ONE scan launch) for a dense search whose
+    plan_info is `plan`: the matrix once + the queries + what the scan kernel writes."""
+    kernel = plan.split(" ")[0].split("<")[0]
+    batched = kernel != "dense_scan_topk_kernel"  # scores S[B, n] are written once and read once
+    two_level = "two-level" in plan  # the scan keeps one maximum per 32-row tile and query, not every score
+    hi = kernel == "dense_hi_tilemax_kernel"  # fp16 first pass: <= 64 queries per scan, maxima rows padded to 16 queries
+    per_scan = int(plan.split("queries_per_launch=")[1].split()[0]) if "queries_per_launch=" in plan else B
+    cols = (per_scan + 15) // 16 * 16 if hi else per_scan
+    nbytes = float(n) * d * 4 + per_scan * d * 4 + (
+        (float(n) / 32 * cols * 4 if two_level else float(n) * per_scan * 4) if batched else B * k * 8)
+    return kernel, hi, per_scan, nbytes
+
+
 def _hbm_scan_one(torch, _native, device, X, Q, n, d, B, steps, warmup, k):
     idx = _native.DenseIndex(device_ptr=X.data_ptr(), n=n, dim=d, device=device.index, keepalive=X)
     idx.reserve(B, k)
@@ -653,11 +667,27 @@ def _hbm_scan_one(torch, _native, device, X, Q, n, d, B, steps, warmup, k):
     es, ei = OD.flatip_topk(X[:npre].cpu().numpy(), Qh, k)
     agree = float(np.mean(gi == ei))
     maxerr = float(np.max(np.abs(gs - es)))
-    kernel = plan.split(" ")[0].split("<")[0]
-    batched = kernel != "dense_scan_topk_kernel"  # scores S[B, n] are written once and read once
-    two_level = "two-level" in plan  # the scan keeps one maximum per 32-row tile and query, not every score
-    bytes_per_launch = float(n) * d * 4 + B * d * 4 + ((float(n) / 32 * B * 4 if two_level else float(n) * B * 4)
-                                                       if batched else B * k * 8)
+    kernel, hi, per_scan, bytes_per_launch = scan_algorithmic_bytes(plan, n, d, B, k)
+    extra = {}
+    if hi:
+        # the fp16 first pass only picks candidate tiles: ids and score bits must be those of the exact first pass, on
+        # the FULL matrix; and how many queries its rounding bound could not resolve (their batches also ran the exact pass)
+        took, unresolved = idx.hi_counters()
+        hs, hids = s.cpu().numpy().copy(), i.cpu().numpy().copy()
+        os.environ["AMDR_DENSE_HI"] = "0"
+        try:
+            ex = _native.DenseIndex(device_ptr=X.data_ptr(), n=n, dim=d, device=device.index, keepalive=X)
+            es_, ei_ = torch.empty_like(s), torch.empty_like(i)
+            ex.search_device(Q[off:].data_ptr(), B, k, es_.data_ptr(), ei_.data_ptr(), st)
+            torch.cuda.synchronize()
+            same = bool(np.array_equal(ei_.cpu().numpy(), hids) and
+                        np.array_equal(es_.cpu().numpy().view(np.uint32), hs.view(np.uint32)))
+            ex.close()
+        finally:
+            del os.environ["AMDR_DENSE_HI"]
+        extra = {"fp16_first_pass": {"queries": took, "unresolved_by_the_rounding_bound": unresolved,
+                                     "full_matrix_ids_and_score_bits_equal_exact_first_pass": same,
+                                     "queries_per_scan": per_scan}}
     per_launch_ms = scan_ms / max(launches, 1)
     achieved = bytes_per_launch / (per_launch_ms * 1e-3) / 1e9
     out = {"workload": f"synthetic {n}x{d} fp32 rows in HBM, {B} queries/scan, top-{k}", "kernel": kernel, "plan": plan,
@@ -665,8 +695,8 @@ def _hbm_scan_one(torch, _native, device, X, Q, n, d, B, steps, warmup, k):
            "scan_kernel_ms": per_launch_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
            "achieved_GBs": achieved, "peak_GBs": HBM_PEAK_GBS, "frac": achieved / HBM_PEAK_GBS,
            "traffic": pmc_traffic(f"synth10m_b{B}", kernel) if (n == 10_000_000 and d == 768) else None,
-           "f32_TFLOPs": 2.0 * n * d * B / (per_launch_ms * 1e-3) / 1e12,
-           "oracle_prefix_rows": npre, "oracle_id_agreement": agree, "oracle_max_abs_err": maxerr}
+           "f32_TFLOPs": None if hi else 2.0 * n * d * B / (per_launch_ms * 1e-3) / 1e12,
+           "oracle_prefix_rows": npre, "oracle_id_agreement": agree, "oracle_max_abs_err": maxerr, **extra}
     idx.close()
     pre.close()
     return out
@@ -737,9 +767,7 @@ def run_scale_synth10m(torch, dist, world, rank, local, device, n_total, B, step
     else:
         per_rank = [per_scan]
     plan = idx.plan_info(B, K)
-    kernel = plan.split(" ")[0].split("<")[0]
-    batched = kernel != "dense_scan_topk_kernel"
-    bytes_per_launch = float(hi - lo) * 768 * 4 + B * 768 * 4 + (float(hi - lo) * B * 4 if batched else B * K * 8)
+    kernel, _, _, bytes_per_launch = scan_algorithmic_bytes(plan, hi - lo, 768, B, K)
     achieved = bytes_per_launch / (per_scan * 1e-3) / 1e9
     out = {"workload": f"synthetic {n_total}x768 fp32 chunk matrix row-sharded over {world} GPU(s), {B} queries/scan, "
                        f"top-{K} (BASELINE configs[4]); per scan: HIP scan of the shard -> all_gather_into_tensor "
@@ -943,7 +971,7 @@ def main():
             for name, fn in (("full_hybrid_rerank_sharded",
                               lambda: run_full_hybrid_rerank(torch, local, K, max(3, min(a.steps, 10)), dist, world, rank)),
                              ("scale_synth10m",
-                              lambda: run_scale_synth10m(torch, dist, world, rank, local, device, a.synth_rows, 32, 10, 3))):
+                              lambda: run_scale_synth10m(torch, dist, world, rank, local, device, a.synth_rows, 64, 10, 3))):
                 try:
                     sc = fn()
                 except Exception as e:  # noqa: BLE001
@@ -952,7 +980,7 @@ def main():
                     result[name] = sc
         if rank == 0 and extras and world == 1 and not a.no_hbm_scan:
             try:
-                result["hbm_scan"] = run_hbm_scan(torch, device, a.synth_rows, 768, [4, 32], steps=20, warmup=3)
+                result["hbm_scan"] = run_hbm_scan(torch, device, a.synth_rows, 768, [4, 32, 64], steps=20, warmup=3)
             except Exception as e:  # noqa: BLE001 - report, never hide
                 result["hbm_scan"] = {"error": repr(e)}
     else:

@@ -91,6 +91,14 @@ int amdr_dense_plan_info(const amdr_dense_t* h, int32_t nq, int32_t k, char* buf
  * maximum any single pass (full chunks and the remainder) then USES — out6[3..5].  Zeros for the 1-4 query forms.
  * A test holds out6[3+i] <= out6[i] over shapes with many row slabs (tests/test_abi.py). */
 int amdr_dense_workspace_plan(int64_t n, int32_t d, int32_t nq, int32_t k, int64_t* out6);
+/* Large scans (chunk matrix far beyond the caches, >= 5 queries): the first pass of the two-level top-k runs on the
+ * fp16 matrix instructions over fp16 roundings of both operands, 64 queries per scan; its candidate cut is widened by a
+ * proven rounding bound and the second pass is the exact fp32 kernel, so ids and score bits are those of the exact
+ * forms (csrc/dense_hi.hip).  A query whose cut the bound does not separate sends its batch through the exact first
+ * pass as well (decided on the device).  out2[0] = queries that took the fp16 first pass since creation, out2[1] =
+ * those it could not resolve.  Synchronises the device.  The matrix wrapped by amdr_dense_create_from_device must not
+ * change while the handle lives (its largest component and row norm are measured at creation). */
+int amdr_dense_hi_counters(amdr_dense_t* h, int64_t* out2);
 /* HIP-event bracket around the scan kernel alone (not the merge), recorded on
  * the stream each search is launched on; used by bench.py for the roofline.
  * begin() arms up to max_launches event pairs, end() returns the summed scan

@@ -30,7 +30,7 @@ EXPORTS = (
     "amdr_last_error", "amdr_version", "amdr_device_count", "amdr_device_name",
     "amdr_dense_create", "amdr_dense_create_from_device", "amdr_dense_add", "amdr_dense_ntotal", "amdr_dense_dim",
     "amdr_dense_reserve", "amdr_dense_search", "amdr_dense_search_device", "amdr_dense_search_fuse_device", "amdr_dense_read_rows", "amdr_dense_score_rows",
-    "amdr_dense_plan_info", "amdr_dense_workspace_plan", "amdr_dense_profile_begin", "amdr_dense_profile_end", "amdr_dense_destroy",
+    "amdr_dense_plan_info", "amdr_dense_workspace_plan", "amdr_dense_hi_counters", "amdr_dense_profile_begin", "amdr_dense_profile_end", "amdr_dense_destroy",
     "amdr_bm25_create", "amdr_bm25_ndocs", "amdr_bm25_reserve", "amdr_bm25_search", "amdr_bm25_search_device",
     "amdr_bm25_scores", "amdr_bm25_destroy",
     "amdr_tokenizer_create", "amdr_tokenizer_encode", "amdr_tokenizer_spans", "amdr_tokenizer_destroy",
@@ -50,7 +50,7 @@ SIGNATURES = {
     "amdr_dense_create": "PliiP", "amdr_dense_create_from_device": "PliiP", "amdr_dense_add": "PPl",
     "amdr_dense_ntotal": "PP", "amdr_dense_dim": "PP", "amdr_dense_reserve": "Pii", "amdr_dense_search": "PPiiPP",
     "amdr_dense_search_device": "PPiiPPP", "amdr_dense_search_fuse_device": "PPiiPPPPiPPPPPPPP", "amdr_dense_read_rows": "PllP", "amdr_dense_score_rows": "PPiPiP",
-    "amdr_dense_plan_info": "PiiPi", "amdr_dense_workspace_plan": "liiiP", "amdr_dense_profile_begin": "Pi", "amdr_dense_profile_end": "PPP", "amdr_dense_destroy": "P",
+    "amdr_dense_plan_info": "PiiPi", "amdr_dense_workspace_plan": "liiiP", "amdr_dense_hi_counters": "PP", "amdr_dense_profile_begin": "Pi", "amdr_dense_profile_end": "PPP", "amdr_dense_destroy": "P",
     "amdr_bm25_create": "PPPPPlldddiP", "amdr_bm25_ndocs": "PP", "amdr_bm25_reserve": "Piil",
     "amdr_bm25_search": "PPPiiPP", "amdr_bm25_search_device": "PPPiiPPP", "amdr_bm25_scores": "PPPiP",
     "amdr_bm25_destroy": "P",
@@ -249,6 +249,13 @@ class DenseIndex:
         _check(load().amdr_dense_plan_info(self._h, C.c_int32(nq), C.c_int32(k), buf, C.c_int32(512)),
                "amdr_dense_plan_info")
         return buf.value.decode()
+
+    def hi_counters(self) -> Tuple[int, int]:
+        """(queries that took the fp16 first pass of large scans, those it could not resolve — their batches also
+        ran the exact first pass).  Synchronises the device."""
+        out = (C.c_int64 * 2)()
+        _check(load().amdr_dense_hi_counters(self._h, out), "amdr_dense_hi_counters")
+        return int(out[0]), int(out[1])
 
     def profile_begin(self, max_launches: int) -> None:
         _check(load().amdr_dense_profile_begin(self._h, C.c_int32(max_launches)), "amdr_dense_profile_begin")

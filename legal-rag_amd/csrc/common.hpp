@@ -83,14 +83,27 @@ struct DenseMfmaPlan {
 bool dense_mfma_supported(int d);
 void dense_mfma_plan(long n, int d, int nq, int k, DenseMfmaPlan* p);
 // mode 0: every row's score; 1: per-tile maxima; 2: re-scoring of the tiles in tile_list (dense_mfma.hip)
+// `gate` (nullable device int): the launch does nothing unless *gate != 0 — the exact first pass behind the fp16 one
+// (dense_hi.hip) is enqueued unconditionally and decides on the device whether it runs
 int dense_mfma_launch_scores(const DenseMfmaPlan& p, const float* X, long n, int d, const float* Q, int nq, float* S,
                              hipStream_t st, int mode = 0, const int* tile_list = nullptr,
-                             const int* tile_count = nullptr, long n_real = 0);
+                             const int* tile_count = nullptr, long n_real = 0, const int* gate = nullptr);
 // two-level top-k helpers: sorted unique list of the candidate tiles; column -> row id of the final hits
-int dense_tiles_unique_launch(const int64_t* tile_ids, int n_in, int* list, int* count, hipStream_t st);
-int dense_tiles_remap_launch(int64_t* ids, int total, const int* list, const int* count, long n_real, hipStream_t st);
+int dense_tiles_unique_launch(const int64_t* tile_ids, int n_in, long n_tiles, int* list, int* count, hipStream_t st,
+                              const int* gate = nullptr);
+int dense_tiles_remap_launch(int64_t* ids, int total, const int* list, const int* count, long n_real, hipStream_t st,
+                             const int* gate = nullptr);
 int dense_mfma_launch_topk(const DenseMfmaPlan& p, const float* S, long n, int nq, int k, void* part,
-                           float* fin_scores, int64_t* fin_ids, hipStream_t st);
+                           float* fin_scores, int64_t* fin_ids, hipStream_t st, const int* gate = nullptr);
+
+// ---- fp16 first pass of the two-level top-k on large matrices: dense_hi.hip ----
+bool dense_hi_supported(int d);
+size_t dense_hi_mt_bytes(long n);
+int dense_hi_launch_tilemax(const float* X, long n, int d, const float* Q, int nq, float* MT, hipStream_t st, float x_scale);
+int dense_hi_launch_transpose(const float* MT, long n, int nq, long ldM, float* M, hipStream_t st);
+int dense_hi_launch_check(const float* vals, int m, int kc1, int k, const float* Q, int d, float row_norm_max, float x_scale,
+                          long n_tiles, int* flag, unsigned int* unresolved, hipStream_t st);
+int dense_stats_launch(const float* X, long n, int d, unsigned int* out2, hipStream_t st);
 
 
 // ---- dense top-k + fusion in one call (fuse.hip; dense.hip amdr_dense_search_fuse_device) ----

@@ -197,8 +197,10 @@ __global__ __launch_bounds__(256) void dense_all_scores_kernel(const float* __re
 // One block per query: stream the per-block lists, keep the best k, decode.
 __global__ __launch_bounds__(256) void dense_merge_kernel(const C32* __restrict__ part, int nparts, int nq, int k,
                                                            int cap, float* __restrict__ out_scores,
-                                                           long long* __restrict__ out_ids) {
+                                                           long long* __restrict__ out_ids,
+                                                           const int* __restrict__ gate) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (gate != nullptr && *gate == 0) return;  // gated launch: see run_search_two_level
   C32* lists = reinterpret_cast<C32*>(smem);
   int* cnts = reinterpret_cast<int*>(lists + (size_t)kWaves * cap);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -307,6 +309,12 @@ struct amdr_dense {
   // therefore never scribble over the score matrix of a search_batch still in flight on another
   // stream.  "_device" calls on ONE handle from SEVERAL streams remain the caller's to order.
   DevBuf part[2], smat[2], aux[2], qbuf, sbuf, ibuf;  // aux: candidate tiles of the two-level top-k
+  // matrix statistics for the fp16 first pass of large scans (dense_hi.hip): kept up to date by create / add
+  DevBuf stats;
+  float x_scale = 1.f;       // power of two: |x| * x_scale < 1 for every component
+  float row_norm_max = 0.f;  // largest row L2 norm
+  bool hi_ok = false;        // d supported and both statistics finite
+  int64_t hi_queries = 0;    // queries that went through the fp16 first pass (amdr_dense_hi_counters)
   // optional HIP-event ring bracketing the scan kernel alone (bench.py roofline)
   std::vector<hipEvent_t> prof_ev;
   int prof_used = 0;
@@ -461,7 +469,7 @@ int run_search_batched(amdr_dense* h, int ws, const float* Q_dev, int nq, int k,
     if (!direct) {
       size_t lds = (size_t)kWaves * p.cap * sizeof(C32) + kWaves * sizeof(int);
       hipLaunchKernelGGL(dense_merge_kernel, dim3(m), dim3(256), lds, st, partb.as<C32>(), p.slabs, m, k, p.cap,
-                         scores_dev + (size_t)q0 * k, (long long*)ids_dev + (size_t)q0 * k);
+                         scores_dev + (size_t)q0 * k, (long long*)ids_dev + (size_t)q0 * k, (const int*)nullptr);
       AMDR_HIP(hipGetLastError());
     }
     if (tail && (rc = dense_fuse_plain_launch(*tail, q0, m, k, scores_dev + (size_t)q0 * k, ids_dev + (size_t)q0 * k, st)))
@@ -496,20 +504,50 @@ int two_level_chunk(int nq, int k) {
   if (c > 96) c = 96;
   return nq < c ? nq : c;
 }
+
+// The fp16 first pass (dense_hi.hip): the tile maxima of step 1 come from v_mfma_f32_32x32x16_f16 on fp16 roundings of
+// both operands — 64 queries per scan instead of 32, the scan bound by HBM alone.  Approximate maxima a(t) lie within
+// eps_q of the exact ones (dense_hi_check_kernel states the bound), so the candidate set is widened: the kc = k +
+// max(k, 22) + 1 tiles with the largest a(t) are re-scored, and the answer is exact if the kc-th largest a(t) lies below
+// T_k - 2 eps_q (T_k = the k-th largest): the k tiles on top have exact maxima >= T_k - eps, hence s_k >= T_k - eps,
+// and a tile holding a row >= s_k has a(t) >= s_k - eps >= T_k - 2 eps — it is among the first kc - 1.  Steps 3-4 are
+// the unchanged exact kernels: same ids, same score bits.  A query the bound does not separate raises a device flag;
+// the exact chain is enqueued behind, every launch gated on that flag (no host round trip), and rewrites the batch.
+// extra candidates: the tiles expected within 2 eps below the cut grow with k (about 0.4 k on unit-norm Gaussian rows)
+int hi_kc(int k) { return k + (k > 22 ? k : 22) + 1; }
+bool hi_applies(const amdr_dense* h, int nq, int k) {
+  const char* e = getenv("AMDR_DENSE_HI");
+  if (e && e[0] == '0') return false;
+  const char* e2 = getenv("AMDR_DENSE_TWO_LEVEL");
+  if (e2 && e2[0] == '0') return false;
+  if (!(h->hi_ok && nq >= kBatchedMin && h->n > 0 && dense_mfma_supported(h->d))) return false;
+  if (hi_kc(k) > AMDR_MAX_K) return false;
+  const long tiles = ((long)h->n + 31) / 32;
+  if (e && e[0] == '1') return tiles >= 2L * hi_kc(k);  // pinned on (tests)
+  return dense_stream_nontemporal((long)h->n, h->d) && tiles >= 64L * hi_kc(k);
+}
+int hi_chunk(int nq, int k) {
+  int c = kTwoLevelTilesMax / hi_kc(k);  // >= 32 for every admitted k
+  if (c > 64) c = 64;
+  return nq < c ? nq : c;
+}
+
 struct TwoLevelPlan {
-  DenseMfmaPlan scan, tk1, pass2;  // full scan (mode 1), top-k over the tile maxima, candidate re-scoring + its top-k
+  DenseMfmaPlan scan, tk1, pass2;  // full scan (mode 1), top-kc over the tile maxima, candidate re-scoring + its top-k
   long tiles, cand_rows;
   size_t m_bytes, s2_bytes, aux_bytes, part_bytes;
 };
-void two_level_plan(const amdr_dense* h, int m, int k, TwoLevelPlan* t) {
+// kc = candidate tiles per query: k in the exact form, hi_kc(k) behind the fp16 first pass
+void two_level_plan(const amdr_dense* h, int m, int k, int kc, TwoLevelPlan* t) {
   t->tiles = ((long)h->n + 31) / 32;
   dense_mfma_plan((long)h->n, h->d, m, k, &t->scan);
-  dense_mfma_plan(t->tiles, h->d, m, k, &t->tk1);  // only its top-k half is used: columns = tiles
-  t->cand_rows = (long)m * k * 32;
+  dense_mfma_plan(t->tiles, h->d, m, kc, &t->tk1);  // only its top-k half is used: columns = tiles
+  t->cand_rows = (long)m * kc * 32;
   dense_mfma_plan(t->cand_rows, h->d, m, k, &t->pass2);
   t->m_bytes = ((size_t)m * t->tk1.ld * sizeof(float) + 255) / 256 * 256;
   t->s2_bytes = (size_t)m * t->pass2.ld * sizeof(float);
-  t->aux_bytes = (size_t)m * k * (sizeof(int64_t) + sizeof(float)) + (size_t)(m * k + 64) * sizeof(int) + 256;
+  if (kc != k) t->s2_bytes = (t->s2_bytes + 255) / 256 * 256 + dense_hi_mt_bytes((long)h->n);  // + MT behind S2
+  t->aux_bytes = (size_t)m * kc * (sizeof(int64_t) + sizeof(float)) + (size_t)(m * kc + 64) * sizeof(int) + 256;
   t->part_bytes = t->tk1.part_bytes > t->pass2.part_bytes ? t->tk1.part_bytes : t->pass2.part_bytes;
 }
 // Workspace for one search of nq queries at depth k: the maximum over every chunk size the pass loop will use — the
@@ -522,17 +560,28 @@ struct TwoLevelNeed {
   void add(const TwoLevelPlan& t) {
     smat = t.m_bytes + t.s2_bytes > smat ? t.m_bytes + t.s2_bytes : smat;
     part = t.part_bytes > part ? t.part_bytes : part;
-    aux = t.aux_bytes > aux ? t.aux_bytes : aux;
+    aux = t.aux_bytes + 256 > aux ? t.aux_bytes + 256 : aux;  // + the gate flag behind the lists
   }
 };
-void two_level_need(const amdr_dense* h, int nq, int k, TwoLevelNeed* need) {
+void two_level_need_exact(const amdr_dense* h, int nq, int k, TwoLevelNeed* need) {
   const int chunk = two_level_chunk(nq, k);
   TwoLevelPlan t;
-  two_level_plan(h, chunk, k, &t);
+  two_level_plan(h, chunk, k, k, &t);
   need->add(t);
   if (nq % chunk) {
-    two_level_plan(h, nq % chunk, k, &t);
+    two_level_plan(h, nq % chunk, k, k, &t);
     need->add(t);
+  }
+}
+void two_level_need(const amdr_dense* h, int nq, int k, TwoLevelNeed* need) {
+  if (!hi_applies(h, nq, k)) return two_level_need_exact(h, nq, k, need);
+  const int chunk = hi_chunk(nq, k);
+  TwoLevelPlan t;
+  for (int m : {chunk, nq % chunk}) {
+    if (m == 0) continue;
+    two_level_plan(h, m, k, hi_kc(k), &t);
+    need->add(t);
+    two_level_need_exact(h, m, k, need);  // the gated exact chain of the same pass
   }
 }
 int two_level_ensure(amdr_dense* h, int ws, int nq, int k, bool all = false) {
@@ -543,11 +592,17 @@ int two_level_ensure(amdr_dense* h, int ws, int nq, int k, bool all = false) {
     for (int kk = 1; kk <= k; ++kk) {
       // a call's path is chosen on its whole batch; its passes (full chunks and a remainder of ANY size) then
       // all run the two-level form: cover every m a pass can have
-      if (!two_level_applies(h, nq < 95 ? nq : 95, kk) && !two_level_applies(h, nq, kk)) continue;
-      const int cmax = two_level_chunk(nq, kk);
+      const bool hi = hi_applies(h, nq, kk);
+      if (!hi && !two_level_applies(h, nq < 95 ? nq : 95, kk) && !two_level_applies(h, nq, kk)) continue;
       TwoLevelPlan t;
+      if (hi)
+        for (int m = 1; m <= hi_chunk(nq, kk); ++m) {
+          two_level_plan(h, m, kk, hi_kc(kk), &t);
+          need.add(t);
+        }
+      const int cmax = two_level_chunk(nq, kk);
       for (int m = 1; m <= cmax; ++m) {
-        two_level_plan(h, m, kk, &t);
+        two_level_plan(h, m, kk, kk, &t);
         need.add(t);
       }
     }
@@ -560,64 +615,104 @@ int two_level_ensure(amdr_dense* h, int ws, int nq, int k, bool all = false) {
 
 // one top-k pass over a [m][ld] score matrix with `cols` valid columns (slab lists + merge, or direct)
 int topk_pass(const DenseMfmaPlan& p, const float* S, long cols, int m, int k, DevBuf& partb, float* out_scores,
-              int64_t* out_ids, hipStream_t st) {
+              int64_t* out_ids, hipStream_t st, const int* gate = nullptr) {
   const bool direct = p.slabs == 1;
-  int rc = dense_mfma_launch_topk(p, S, cols, m, k, partb.p, direct ? out_scores : nullptr, direct ? out_ids : nullptr, st);
+  int rc = dense_mfma_launch_topk(p, S, cols, m, k, partb.p, direct ? out_scores : nullptr, direct ? out_ids : nullptr, st,
+                                  gate);
   if (rc) return rc;
   if (!direct) {
     size_t lds = (size_t)kWaves * p.cap * sizeof(C32) + kWaves * sizeof(int);
     hipLaunchKernelGGL(dense_merge_kernel, dim3(m), dim3(256), lds, st, partb.as<C32>(), p.slabs, m, k, p.cap, out_scores,
-                       (long long*)out_ids);
+                       (long long*)out_ids, gate);
     AMDR_HIP(hipGetLastError());
   }
   return AMDR_OK;
+}
+
+// One pass of <= chunk queries.  hi: the fp16 first pass with kc = hi_kc(k) candidates, its check raises *flag;
+// otherwise the exact first pass, every launch gated on *gate when given.
+int two_level_pass(amdr_dense* h, int ws, const float* Qc, int m, int k, bool hi, float* out_scores, int64_t* out_ids,
+                   hipStream_t st, int* flag, const int* gate) {
+  const int kc = hi ? hi_kc(k) : k;
+  TwoLevelPlan t;
+  two_level_plan(h, m, k, kc, &t);
+  float* M = h->smat[ws].as<float>();
+  float* S2 = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(h->smat[ws].p) + t.m_bytes);
+  unsigned char* aux = reinterpret_cast<unsigned char*>(h->aux[ws].p);
+  int64_t* tile_ids = reinterpret_cast<int64_t*>(aux);
+  float* tile_max = reinterpret_cast<float*>(aux + (size_t)m * kc * sizeof(int64_t));
+  int* list = reinterpret_cast<int*>(aux + (size_t)m * kc * (sizeof(int64_t) + sizeof(float)));
+  int* count = list + (size_t)m * kc;
+  int rc;
+  float* hi_mt = nullptr;
+  // 1. tile maxima (the scan: this is the launch the profiling events bracket)
+  const bool prof = !gate && h->prof_on && (size_t)(h->prof_used + 2) <= h->prof_ev.size();
+  if (prof) AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
+  if (hi) {
+    float* MT = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(S2) +
+                                         ((size_t)m * t.pass2.ld * sizeof(float) + 255) / 256 * 256);
+    rc = dense_hi_launch_tilemax(h->X, (long)h->n, h->d, Qc, m, MT, st, h->x_scale);
+    hi_mt = MT;
+  } else {
+    DenseMfmaPlan scan = t.scan;
+    scan.ld = t.tk1.ld;
+    rc = dense_mfma_launch_scores(scan, h->X, (long)h->n, h->d, Qc, m, M, st, 1, nullptr, nullptr, 0, gate);
+  }
+  if (rc) return rc;
+  if (prof) {
+    AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
+    h->prof_used += 2;
+  }
+  if (hi && (rc = dense_hi_launch_transpose(hi_mt, (long)h->n, m, t.tk1.ld, M, st))) return rc;
+  // 2. kc candidate tiles per query, their sorted union
+  if ((rc = topk_pass(t.tk1, M, t.tiles, m, kc, h->part[ws], tile_max, tile_ids, st, gate))) return rc;
+  if (hi) h->hi_queries += m;
+  if (hi && (rc = dense_hi_launch_check(tile_max, m, kc, k, Qc, h->d, h->row_norm_max, h->x_scale, t.tiles, flag,
+                                          h->stats.as<unsigned int>() + 2, st)))
+    return rc;
+  if ((rc = dense_tiles_unique_launch(tile_ids, m * kc, t.tiles, list, count, st, gate))) return rc;
+  // 3. exact scores of the candidate tiles' rows
+  if ((rc = dense_mfma_launch_scores(t.pass2, h->X, t.cand_rows, h->d, Qc, m, S2, st, 2, list, count, (long)h->n, gate)))
+    return rc;
+  // 4. top-k of the candidates, columns -> row ids
+  if ((rc = topk_pass(t.pass2, S2, t.cand_rows, m, k, h->part[ws], out_scores, out_ids, st, gate))) return rc;
+  return dense_tiles_remap_launch(out_ids, m * k, list, count, (long)h->n, st, gate);
 }
 
 int run_search_two_level(amdr_dense* h, int ws, const float* Q_dev, int nq, int k, float* scores_dev, int64_t* ids_dev,
                          hipStream_t st) {
   int rc = two_level_ensure(h, ws, nq, k);
   if (rc) return rc;
-  const int chunk = two_level_chunk(nq, k);
+  const bool hi = hi_applies(h, nq, k);
+  const int chunk = hi ? hi_chunk(nq, k) : two_level_chunk(nq, k);
+  // the gate flag: behind the largest list layout of this call (two_level_ensure sized aux for it)
+  int* flag = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(h->aux[ws].p) + h->aux[ws].cap - 256);
   for (int q0 = 0; q0 < nq; q0 += chunk) {
     const int m = nq - q0 < chunk ? nq - q0 : chunk;
-    TwoLevelPlan t;
-    two_level_plan(h, m, k, &t);
-    float* M = h->smat[ws].as<float>();
-    float* S2 = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(h->smat[ws].p) + t.m_bytes);
-    unsigned char* aux = reinterpret_cast<unsigned char*>(h->aux[ws].p);
-    int64_t* tile_ids = reinterpret_cast<int64_t*>(aux);
-    float* tile_max = reinterpret_cast<float*>(aux + (size_t)m * k * sizeof(int64_t));
-    int* list = reinterpret_cast<int*>(aux + (size_t)m * k * (sizeof(int64_t) + sizeof(float)));
-    int* count = list + (size_t)m * k;
     const float* Qc = Q_dev + (size_t)q0 * h->d;
-    // 1. tile maxima (the scan: this is the launch the profiling events bracket)
-    DenseMfmaPlan scan = t.scan;
-    scan.ld = t.tk1.ld;
-    const bool prof = h->prof_on && (size_t)(h->prof_used + 2) <= h->prof_ev.size();
-    if (prof) AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
-    if ((rc = dense_mfma_launch_scores(scan, h->X, (long)h->n, h->d, Qc, m, M, st, 1))) return rc;
-    if (prof) {
-      AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
-      h->prof_used += 2;
+    float* os = scores_dev + (size_t)q0 * k;
+    int64_t* oi = ids_dev + (size_t)q0 * k;
+    if (!hi) {
+      if ((rc = two_level_pass(h, ws, Qc, m, k, false, os, oi, st, nullptr, nullptr))) return rc;
+      continue;
     }
-    // 2. k candidate tiles per query, their sorted union
-    if ((rc = topk_pass(t.tk1, M, t.tiles, m, k, h->part[ws], tile_max, tile_ids, st))) return rc;
-    if ((rc = dense_tiles_unique_launch(tile_ids, m * k, list, count, st))) return rc;
-    // 3. exact scores of the candidate tiles' rows
-    if ((rc = dense_mfma_launch_scores(t.pass2, h->X, t.cand_rows, h->d, Qc, m, S2, st, 2, list, count, (long)h->n)))
-      return rc;
-    // 4. top-k of the candidates, columns -> row ids
-    if ((rc = topk_pass(t.pass2, S2, t.cand_rows, m, k, h->part[ws], scores_dev + (size_t)q0 * k, ids_dev + (size_t)q0 * k,
-                        st)))
-      return rc;
-    if ((rc = dense_tiles_remap_launch(ids_dev + (size_t)q0 * k, m * k, list, count, (long)h->n, st))) return rc;
+    AMDR_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
+    if ((rc = two_level_pass(h, ws, Qc, m, k, true, os, oi, st, flag, nullptr))) return rc;
+    const int ec = two_level_chunk(m, k);  // the exact chain holds 32-query tiles
+    for (int e0 = 0; e0 < m; e0 += ec) {
+      const int em = m - e0 < ec ? m - e0 : ec;
+      if ((rc = two_level_pass(h, ws, Qc + (size_t)e0 * h->d, em, k, false, os + (size_t)e0 * k, oi + (size_t)e0 * k, st,
+                               nullptr, flag)))
+        return rc;
+    }
   }
   return AMDR_OK;
 }
 
 int run_search(amdr_dense* h, int ws, const float* Q_dev, int nq, int k, float* scores_dev, int64_t* ids_dev,
                hipStream_t st) {
-  if (two_level_applies(h, nq, k)) return run_search_two_level(h, ws, Q_dev, nq, k, scores_dev, ids_dev, st);
+  if (hi_applies(h, nq, k) || two_level_applies(h, nq, k))
+    return run_search_two_level(h, ws, Q_dev, nq, k, scores_dev, ids_dev, st);
   if (nq >= kBatchedMin && h->n > 0 && dense_mfma_supported(h->d))
     return run_search_batched(h, ws, Q_dev, nq, k, scores_dev, ids_dev, st);
   if (h->n > 0 && h->n <= kRowWavesMax) return run_search_batched(h, ws, Q_dev, nq, k, scores_dev, ids_dev, st, true);
@@ -649,7 +744,7 @@ int run_search(amdr_dense* h, int ws, const float* Q_dev, int nq, int k, float* 
   int nparts = h->n > 0 ? p.grid_x : 0;
   size_t lds = (size_t)kWaves * p.cap * sizeof(C32) + kWaves * sizeof(int);
   hipLaunchKernelGGL(dense_merge_kernel, dim3(nq), dim3(256), lds, st, part, nparts, nq, k, p.cap, scores_dev,
-                     (long long*)ids_dev);
+                     (long long*)ids_dev, (const int*)nullptr);
   AMDR_HIP(hipGetLastError());
   return AMDR_OK;
 }
@@ -659,6 +754,27 @@ int check_search_args(const amdr_dense* h, const void* Q, int nq, int k, const v
   AMDR_REQUIRE(nq >= 0, "dense: nq=%d", nq);
   AMDR_REQUIRE(k >= 1 && k <= AMDR_MAX_K, "dense: k=%d outside [1,%d]", k, AMDR_MAX_K);
   AMDR_REQUIRE(nq == 0 || (Q && s && i), "dense: null buffer");
+  return AMDR_OK;
+}
+
+// Statistics of rows [row0, row0 + rows) folded into the handle's (max |component|, max row norm): what the fp16 first
+// pass of large scans scales by and bounds its error with.  Synchronous (create / add are).
+int update_stats(amdr_dense* h, int64_t row0, int64_t rows) {
+  h->hi_ok = false;
+  if (!dense_hi_supported(h->d)) return AMDR_OK;
+  int rc = h->stats.ensure(4 * sizeof(unsigned int));  // max |x|, max row norm, unresolved queries (counter), pad
+  if (rc) return rc;
+  if (row0 == 0) AMDR_HIP(hipMemsetAsync(h->stats.p, 0, 4 * sizeof(unsigned int), h->stream));
+  if ((rc = dense_stats_launch(h->X + (size_t)row0 * h->d, (long)rows, h->d, h->stats.as<unsigned int>(), h->stream)))
+    return rc;
+  float st[2] = {0.f, 0.f};
+  AMDR_HIP(hipMemcpyAsync(st, h->stats.p, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+  AMDR_HIP(hipStreamSynchronize(h->stream));
+  int e = 0;
+  if (st[0] > 0.f && st[0] <= FLT_MAX) (void)frexpf(st[0], &e);
+  h->x_scale = ldexpf(1.f, -e);
+  h->row_norm_max = st[1];
+  h->hi_ok = st[0] <= FLT_MAX && st[1] <= FLT_MAX && e > -100 && e < 100;
   return AMDR_OK;
 }
 
@@ -688,6 +804,10 @@ int amdr_dense_create(const float* X_host, int64_t n, int32_t d, int32_t device,
     amdr_dense_destroy(h);
     return fail(e == hipErrorOutOfMemory ? AMDR_ENOMEM : AMDR_EHIP, "dense_create: %s", hipGetErrorString(e));
   }
+  if ((rc = update_stats(h, 0, n))) {
+    amdr_dense_destroy(h);
+    return rc;
+  }
   *out = h;
   return AMDR_OK;
 }
@@ -714,6 +834,10 @@ int amdr_dense_create_from_device(const float* X_dev, int64_t n, int32_t d, int3
     amdr_dense_destroy(h);
     return fail(AMDR_EHIP, "dense_create_from_device: %s", hipGetErrorString(e));
   }
+  if ((rc = update_stats(h, 0, n))) {  // the wrapped matrix must not change while the handle lives
+    amdr_dense_destroy(h);
+    return rc;
+  }
   *out = h;
   return AMDR_OK;
 }
@@ -736,8 +860,9 @@ int amdr_dense_add(amdr_dense_t* h, const float* X_host, int64_t n_add) {
     h->cap_rows = ncap;
   }
   AMDR_HIP(hipMemcpy(h->X + (size_t)h->n * h->d, X_host, (size_t)n_add * h->d * sizeof(float), hipMemcpyHostToDevice));
+  const int64_t row0 = h->n;
   h->n += n_add;
-  return AMDR_OK;
+  return update_stats(h, row0, n_add);
 }
 
 int amdr_dense_ntotal(const amdr_dense_t* h, int64_t* n) {
@@ -763,7 +888,7 @@ int amdr_dense_reserve(amdr_dense_t* h, int32_t nq_max, int32_t k_max) {
   // batches on a large matrix take the two-level form (every batch size <= nq_max and depth <= k_max that does is
   // covered, see two_level_ensure); longer ones the panel kernel + score matrix
   if ((rc = two_level_ensure(h, 0, nq_max, k_max, true))) return rc;
-  if (two_level_applies(h, nq_max, k_max)) {
+  if (hi_applies(h, nq_max, k_max) || two_level_applies(h, nq_max, k_max)) {
   } else if (nq_max >= kBatchedMin && h->n > 0 && dense_mfma_supported(h->d)) {
     DenseMfmaPlan mp;
     const int cmax = batched_chunk(h, nq_max);
@@ -813,7 +938,8 @@ int amdr_dense_search_fuse_device(amdr_dense_t* h, const float* Q_dev, int32_t n
   AMDR_HIP(hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
   FuseTail tail{p, dense_row2uid, bm25_ids, bm25_scores, kb, bm25_row2uid, out_ids, out_vals, out_mask, out_count};
-  if (!two_level_applies(h, nq, k) && nq >= kBatchedMin && h->n > 0 && dense_mfma_supported(h->d))
+  if (!hi_applies(h, nq, k) && !two_level_applies(h, nq, k) && nq >= kBatchedMin && h->n > 0 &&
+      dense_mfma_supported(h->d))
     return run_search_batched(h, 0, Q_dev, nq, k, dense_scores_dev, dense_ids_dev, st, false, &tail);
   if ((rc = run_search(h, 0, Q_dev, nq, k, dense_scores_dev, dense_ids_dev, st))) return rc;
   return dense_fuse_plain_launch(tail, 0, nq, k, dense_scores_dev, dense_ids_dev, st);
@@ -881,16 +1007,27 @@ int amdr_dense_workspace_plan(int64_t n, int32_t d, int32_t nq, int32_t k, int64
   h.d = d;
   for (int i = 0; i < 6; ++i) out6[i] = 0;
   auto mx = [](int64_t& a, size_t b) { a = (int64_t)b > a ? (int64_t)b : a; };
-  if (two_level_applies(&h, nq, k)) {
-    TwoLevelNeed need;
+  h.hi_ok = dense_hi_supported(d);  // shape only: the statistics of a real matrix can only take the fp16 first pass away
+  if (hi_applies(&h, nq, k) || two_level_applies(&h, nq, k)) {
+    TwoLevelNeed need, used;
     two_level_need(&h, nq, k, &need);
     out6[0] = (int64_t)need.smat, out6[1] = (int64_t)need.part, out6[2] = (int64_t)need.aux;
-    const int chunk = two_level_chunk(nq, k);
-    for (int q0 = 0; q0 < nq; q0 += chunk) {
+    const bool hi = hi_applies(&h, nq, k);
+    const int chunk = hi ? hi_chunk(nq, k) : two_level_chunk(nq, k);
+    for (int q0 = 0; q0 < nq; q0 += chunk) {  // what the pass loop of run_search_two_level touches
+      const int m = nq - q0 < chunk ? nq - q0 : chunk;
       TwoLevelPlan t;
-      two_level_plan(&h, nq - q0 < chunk ? nq - q0 : chunk, k, &t);
-      mx(out6[3], t.m_bytes + t.s2_bytes), mx(out6[4], t.part_bytes), mx(out6[5], t.aux_bytes);
+      if (hi) {
+        two_level_plan(&h, m, k, hi_kc(k), &t);
+        used.add(t);
+      }
+      const int ec = hi ? two_level_chunk(m, k) : m;
+      for (int e0 = 0; e0 < m; e0 += ec) {
+        two_level_plan(&h, m - e0 < ec ? m - e0 : ec, k, k, &t);
+        used.add(t);
+      }
     }
+    out6[3] = (int64_t)used.smat, out6[4] = (int64_t)used.part, out6[5] = (int64_t)used.aux;
   } else if (nq >= kBatchedMin && dense_mfma_supported(d)) {
     const int chunk = batched_chunk(&h, nq);
     DenseMfmaPlan p;
@@ -911,10 +1048,21 @@ int amdr_dense_plan_info(const amdr_dense_t* h, int32_t nq, int32_t k, char* buf
     snprintf(buf, buf_len, "empty index");
     return AMDR_OK;
   }
+  if (hi_applies(h, nq, k)) {
+    TwoLevelPlan t;
+    const int m = hi_chunk(nq, k);
+    two_level_plan(h, m, k, hi_kc(k), &t);
+    snprintf(buf, buf_len,
+             "dense_hi_tilemax_kernel fp16 first pass queries_per_launch=%d two-level: top-%d of %ld approximate tile "
+             "maxima, cut checked against the rounding bound + exact re-scoring of <= %d candidate tiles + top-k "
+             "(exact first pass behind a device flag)",
+             m, hi_kc(k), t.tiles, m * hi_kc(k));
+    return AMDR_OK;
+  }
   if (two_level_applies(h, nq, k)) {
     TwoLevelPlan t;
     const int m = two_level_chunk(nq, k);
-    two_level_plan(h, m, k, &t);
+    two_level_plan(h, m, k, k, &t);
     snprintf(buf, buf_len,
              "dense_mfma_scores_kernel tile-maxima grid=%dx%d queries_per_launch=%d two-level: top-%d of %ld tile maxima "
              "+ re-scoring of <= %d candidate tiles + top-k",
@@ -944,6 +1092,21 @@ int amdr_dense_plan_info(const amdr_dense_t* h, int32_t nq, int32_t k, char* buf
   make_plan(h->n, h->d, nq, k, &p);
   snprintf(buf, buf_len, "dense_scan_topk_kernel<NQ=%d> grid=%dx%d%s", p.nq_per_block, p.grid_x, p.grid_y,
            p.grid_x == 1 ? "" : " + dense_merge_kernel");
+  return AMDR_OK;
+}
+
+int amdr_dense_hi_counters(amdr_dense_t* h, int64_t* out2) {
+  AMDR_REQUIRE(h && out2, "dense_hi_counters: null");
+  std::lock_guard<std::mutex> g(h->mu);
+  AMDR_HIP(hipSetDevice(h->device));
+  out2[0] = h->hi_queries;
+  out2[1] = 0;
+  if (h->stats.p) {
+    unsigned int c = 0;
+    AMDR_HIP(hipDeviceSynchronize());  // the counter is bumped by kernels on the callers' streams
+    AMDR_HIP(hipMemcpy(&c, h->stats.as<unsigned int>() + 2, sizeof(c), hipMemcpyDeviceToHost));
+    out2[1] = (int64_t)c;
+  }
   return AMDR_OK;
 }
 
@@ -996,6 +1159,7 @@ int amdr_dense_destroy(amdr_dense_t* h) {
   h->qbuf.release();
   h->sbuf.release();
   h->ibuf.release();
+  h->stats.release();
   delete h;
   return AMDR_OK;
 }

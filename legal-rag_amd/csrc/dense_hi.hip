@@ -1,0 +1,363 @@
+// Dense channel, large scans: the FIRST pass of the two-level top-k on the fp16 matrix instructions.
+//
+// The two-level top-k of dense.hip (run_search_two_level) scans the chunk matrix once for per-tile maxima, picks
+// the candidate tiles of every query and re-scores those exactly.  With 32 queries per scan the exact-fp32 MFMAs of
+// the first pass alone need 4.6 ms on the 10 M x 768 matrix, HBM alone 4.45 ms: the pass runs at 0.73 of the HBM
+// peak and cannot hold more than 32 queries (a 96-KiB fp32 query tile in LDS).  The first pass only has to find
+// candidate tiles, and the second pass is exact — so here it runs on v_mfma_f32_32x32x16_f16 with fp16 ROUNDINGS of
+// both operands (hi parts, csrc/maxsim.hip): 16x the matrix rate, a 96-KiB tile now holds 64 queries, the scan is
+// bound by HBM alone.  |x^ . q^ - x . q| <= (2^-10 + 2^-22 + 768 * 2^-24) |x| |q| is a proven bound, the candidate
+// cut is widened by it (dense.hip run_search_hi_two_level), the re-scoring pass is the unchanged exact fp32 kernel:
+// ids and score bits are those of the exact forms.  A query whose cut the bound does not separate (mass near-ties)
+// raises a device flag and the exact first pass runs for that batch (gated launches: no host round trip).
+//
+// Kernel: a block = 8 waves; the query tile — up to 64 queries converted to fp16 (per-query power-of-two scale) —
+// sits in LDS for the whole block; every wave streams 32-row tiles of X: coalesced 16-B/lane fp32 loads (4 rows x
+// 256 B per wave instruction, non-temporal, 2 chunks of 64 floats per row in flight), conversion to fp16 in
+// registers (the matrix's power-of-two scale applied), a wave-private 4-KiB fp16 stage in LDS, fragments back, 8
+// MFMAs per 64-float chunk (32 rows x 64 queries).  Per tile and query only the MAXIMUM leaves the kernel.
+#include "common.hpp"
+#include "topk.hpp"
+
+#include <cfloat>
+#include <cmath>
+#include <cstdlib>
+
+namespace amdr {
+
+typedef float hi4f __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+constexpr int kHiWaves = 8;
+constexpr int kHiKC = 64;              // floats of every row per chunk
+constexpr int kHiStageBytes = 32 * 128;  // 32 rows x 64 halves
+
+// stage: row r (0..31) at byte r*128, its 16-B slot s (0..7) at s ^ ((r >> 1) & 7) (the image of dense_mfma.hip's stage)
+__device__ __forceinline__ int hi_stage_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
+// query tile: row q (0..63) at byte q * (d * 2), its 16-B chunk c at c ^ (q & 15) (rows alias on the banks: d * 2 % 256 == 0)
+__device__ __forceinline__ int hi_q_off(int q, int chunk, int d) { return q * (d * 2) + ((chunk ^ (q & 15)) << 4); }
+
+// grid: 1-D over row slabs; LDS: 64 x d halves (query tile) + kHiWaves x 4 KiB (stages).  M[q][tile] is the maximum of
+// (x * x_scale) . (q * 2^-e_q) over the tile's rows — a per-query positive scaling of the scores, which is all a
+// per-query ranking of tiles needs; keeping the scaled value keeps it clear of fp32's subnormal range
+template <int D64>  // d / 64
+__global__ __launch_bounds__(kHiWaves * 64) void dense_hi_tilemax_kernel(const float* __restrict__ X, long n,
+                                                                         const float* __restrict__ Q, int nq,
+                                                                         float* __restrict__ MT /*[tiles][cols]*/,
+                                                                         int cols, float x_scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int d = D64 * 64;
+  constexpr int NCH = D64;
+  unsigned char* qt = smem;
+  unsigned char* stage = smem + 64 * d * 2 + (threadIdx.x >> 6) * kHiStageBytes;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r32 = lane & 31, h = lane >> 5;
+
+  // ---- the query tile: wave w converts queries 8 w .. 8 w + 7 (scale = 2^-e of the query's largest |component|)
+  for (int qi = wave * 8; qi < wave * 8 + 8; ++qi) {
+    const bool live = qi < nq;
+    const float* src = Q + (size_t)(live ? qi : 0) * d;
+    float v[D64];
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < D64; ++j) {
+      v[j] = live ? src[j * 64 + lane] : 0.f;
+      m = fmaxf(m, fabsf(v[j]));
+    }
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) m = fmaxf(m, __shfl_xor(m, sft));
+    int e = 0;
+    if (m > 0.f && m <= FLT_MAX) (void)frexpf(m, &e);
+    const float sc = ldexpf(1.f, -e);
+    _Float16* row = reinterpret_cast<_Float16*>(qt);
+#pragma unroll
+    for (int j = 0; j < D64; ++j) {
+      const int k = j * 64 + lane;  // element k of the query: chunk k >> 3, half k & 7
+      row[(hi_q_off(qi, k >> 3, d) >> 1) + (k & 7)] = (_Float16)(v[j] * sc);
+    }
+  }
+  __syncthreads();
+
+  // Persistent block (one per CU: the query tile is converted once).  Every wave of the grid owns one contiguous run
+  // of tiles (run lengths differ by at most one tile) and streams it front to back; its loads run two 64-float chunks
+  // ahead, across tile boundaries.
+  const long tiles = (n + 31) >> 5;
+  const long gw = (long)blockIdx.x * kHiWaves + wave, nw = (long)gridDim.x * kHiWaves;
+  const long t_lo = tiles * gw / nw, t_hi = tiles * (gw + 1) / nw;
+  // loader role inside a 1-KiB piece: 4 rows x 256 B; lane: row l >> 4, 16-B piece l & 15 (4 floats)
+  const int lrow = lane >> 4, lpiece = lane & 15;
+  auto row_ptr = [&](long tile, int p) {
+    long r = tile * 32 + 4 * p + lrow;
+    if (r >= n) r = n - 1;  // rows past the end repeat the last row: no effect on a maximum
+    return X + (size_t)r * d + lpiece * 4;
+  };
+  hi4f G[2][8];
+  const float* gpn[8];
+  if (t_lo < t_hi) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) gpn[p] = row_ptr(t_lo, p);
+    // issue order = the steady state's (chunk 0's loads, then chunk 1's): the loop header's vmcnt waits are the
+    // minimum over this entry and the back edge, an interleaved order here would drain the queue at every tile start
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+      for (int p = 0; p < 8; ++p) G[c][p] = __builtin_nontemporal_load(reinterpret_cast<const hi4f*>(gpn[p] + c * kHiKC));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float mt[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) mt[j] = 0.f;
+  for (long t = t_lo; t < t_hi; ++t) {
+    const bool has_next = t + 1 < t_hi;
+    const float* gp[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      gp[p] = gpn[p];
+      gpn[p] = row_ptr(has_next ? t + 1 : t, p);
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[b][j] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      // chunk c: fp32 -> fp16 (4 floats -> 8 bytes per piece), into the stage: row 4 p + lrow, 8-byte half (lpiece & 1) of
+      // 16-B slot lpiece >> 1
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const hi4f x = G[c & 1][p];
+        h4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = (_Float16)(x[e] * x_scale);
+        *reinterpret_cast<h4*>(stage + hi_stage_off(4 * p + lrow, lpiece >> 1) + (lpiece & 1) * 8) = y;
+      }
+      // the refill is issued HERE, two chunks ahead of its use (hipcc otherwise sinks the loads towards their first use
+      // and the wave waits a full memory latency per chunk: sched_barrier pins them)
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 2 < NCH) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+          G[c & 1][p] = __builtin_nontemporal_load(reinterpret_cast<const hi4f*>(gp[p] + (c + 2) * kHiKC));
+      } else {  // NCH is even: chunk c + 2 - NCH of the next tile lands in the buffer of its parity.  Unconditional (the
+                // run's last tile re-reads its own first chunks): behind a branch hipcc drains vmcnt to 0 at every tile end
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+          G[c & 1][p] = __builtin_nontemporal_load(reinterpret_cast<const hi4f*>(gpn[p] + (c + 2 - NCH) * kHiKC));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      wave_lds_fence();
+      // fragments: A = row r32, chunks 2 s + h (s = 0..3) of the stage; B = query r32 (+ 32), chunks 8 c + 2 s + h of its row
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const h8 a = *reinterpret_cast<const h8*>(stage + hi_stage_off(r32, 2 * s + h));
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const h8 q = *reinterpret_cast<const h8*>(qt + hi_q_off(32 * b + r32, 8 * c + 2 * s + h, d));
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, q, acc[b], 0, 0, 0);
+        }
+      }
+      wave_lds_fence();  // the next chunk overwrites the stage
+    }
+    // tile maximum per query: 16 rows in the lane's registers, the other 16 in lane ^ 32; lane l keeps query l's
+    float mq[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      float m = acc[b][0];
+#pragma unroll
+      for (int j = 1; j < 16; ++j) m = fmaxf(m, acc[b][j]);
+      mq[b] = fmaxf(m, __uint_as_float(lane_xor<32>(__float_as_uint(m))));
+    }
+    // In the scaled units of the lane's query (see the check kernel).  MT[tile][cols], cols = the queries rounded up to
+    // 16: one contiguous row per tile, the rows of a wave's run back to back.  Two measured facts shape this (timing-only build without any store:
+    // 4.38 ms per scan): written [query][tile], every tile's 64 maxima went to 64 different DRAM pages — 20 M scattered
+    // partial writes that cost 0.9 ms; and a store in the wave's instruction stream holds back the vmcnt of every load
+    // issued after it until it is acknowledged (~3 us a time) — one store per tile cost 0.47 ms even with contiguous rows.
+    // Hence: the maxima of 8 tiles wait in registers and leave as 8 back-to-back row stores, 19 times per wave.
+    const float mine = h ? mq[1] : mq[0];
+    const int j8 = (int)((t - t_lo) & 7);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mt[j] = j8 == j ? mine : mt[j];
+    if (j8 == 7 || !has_next) {  // wave-uniform
+      float* dst = MT + (size_t)(t - j8) * cols + lane;
+      if (lane < cols) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j <= j8) dst[(size_t)j * cols] = mt[j];
+      }
+    }
+  }
+}
+
+// MT[tile][cols] -> M[q][tile] (the layout the top-k pass reads): 256 tiles per block through LDS, 1-KiB runs per query row
+constexpr int kHiTrTiles = 256;
+__host__ __device__ inline int hi_mt_cols(int nq) { return (nq + 15) & ~15; }
+__global__ __launch_bounds__(256) void dense_hi_transpose_kernel(const float* __restrict__ MT, long tiles, int nq, long ldM,
+                                                                 float* __restrict__ M) {
+  __shared__ float patch[kHiTrTiles][65];
+  const long t0 = (long)blockIdx.x * kHiTrTiles;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cols = hi_mt_cols(nq);
+  for (int r = wave; r < kHiTrTiles; r += 4)
+    if (t0 + r < tiles && lane < cols) patch[r][lane] = MT[(size_t)(t0 + r) * cols + lane];
+  __syncthreads();
+  for (int q = wave; q < nq; q += 4) {
+#pragma unroll
+    for (int j = 0; j < kHiTrTiles / 64; ++j) {
+      const int r = lane + 64 * j;
+      if (t0 + r < tiles) M[(size_t)q * ldM + t0 + r] = patch[r][q];
+    }
+  }
+}
+
+// largest |component| and largest row L2 norm of a matrix (float bits; both are non-negative)
+__global__ __launch_bounds__(256) void dense_stats_kernel(const float* __restrict__ X, long n, int d,
+                                                          unsigned int* __restrict__ out2) {
+  const int lane = threadIdx.x & 63;
+  const long wv = ((long)blockIdx.x * 256 + threadIdx.x) >> 6, nw = (long)gridDim.x * 4;
+  float amax = 0.f, nmax = 0.f;
+  for (long r = wv; r < n; r += nw) {
+    float ss = 0.f;
+    for (int k = lane; k < d; k += 64) {
+      const float x = X[(size_t)r * d + k];
+      amax = fmaxf(amax, fabsf(x));
+      ss += x * x;
+    }
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) ss += __shfl_xor(ss, sft);
+    nmax = fmaxf(nmax, sqrtf(ss));
+  }
+#pragma unroll
+  for (int sft = 1; sft < 64; sft <<= 1) amax = fmaxf(amax, __shfl_xor(amax, sft));
+  if (lane == 0) {
+    atomicMax(out2, __float_as_uint(amax != amax ? INFINITY : amax));
+    atomicMax(out2 + 1, __float_as_uint(nmax != nmax ? INFINITY : nmax));
+  }
+}
+
+// After the top-kc1 of the approximate tile maxima (vals [m][kc1], descending, in each query's scaled units): is every
+// tile that can hold one of a query's k best rows among its first kc1 - 1?  Yes if the kc1-th maximum lies below
+// T_k - 2 eps_q (T_k = the k-th largest approximate maximum): the k tiles on top have exact maxima >= T_k - eps, so
+// the k-th best score s_k >= T_k - eps, and a tile holding a row >= s_k has an approximate maximum >= T_k - 2 eps.
+// Otherwise the flag is raised: the exact first pass runs for this batch.
+//
+// eps_q, in scaled units (x' = x * 2^-ex, |x'| < 1; q' = q * 2^-eq, |q'| < 1): per component the fp16 rounding is
+// |dx'| <= 2^-11 |x'| + 2^-25 (the second term covers fp16's subnormal range), the same for q'.  Hence
+//   |x^ . q^ - x' . q'| <= (2^-10 + 2^-22) |x'| |q'| + 2^-25 (|q'|_1 + |x'|_1) (1 + 2^-11) <= ... + d 2^-24 (1 + 2^-11)
+// (the products of two fp16 values are exact in the MFMA's fp32, the accumulation of d of them adds d 2^-24 |x'| |q'|;
+// so does the accumulation inside the exact kernel this pass is compared with).  |x'| <= R * 2^-ex with R the largest
+// row norm.  The comparison only holds if the exact fp32 scores neither overflow nor sink into fp32's subnormal
+// range: |ex + eq| <= 100 is required, else the flag is raised.
+__global__ __launch_bounds__(64) void dense_hi_check_kernel(const float* __restrict__ vals, int kc1, int k,
+                                                            const float* __restrict__ Q, int d, float row_norm_max,
+                                                            float x_scale, int x_exp, long n_tiles,
+                                                            int* __restrict__ flag, unsigned int* __restrict__ unresolved) {
+  const int q = blockIdx.x, lane = threadIdx.x;
+  float amax = 0.f;
+  bool nan = false;
+  for (int j = lane; j < d; j += 64) {
+    const float x = Q[(size_t)q * d + j];
+    nan |= x != x;
+    amax = fmaxf(amax, fabsf(x));
+  }
+#pragma unroll
+  for (int sft = 1; sft < 64; sft <<= 1) amax = fmaxf(amax, __shfl_xor(amax, sft));
+  nan = __any(nan);
+  int e = 0;
+  if (amax > 0.f && amax <= FLT_MAX) (void)frexpf(amax, &e);
+  const float sc = ldexpf(1.f, -e);  // the tile kernel's scale of this query
+  float ss = 0.f;
+  for (int j = lane; j < d; j += 64) {
+    const float x = Q[(size_t)q * d + j] * sc;
+    ss += x * x;
+  }
+#pragma unroll
+  for (int sft = 1; sft < 64; sft <<= 1) ss += __shfl_xor(ss, sft);
+  if (lane != 0) return;
+  const float rel = 1.125f * (9.765625e-4f + 2.4e-7f + 2.f * (float)(d + 8) * 5.9604645e-8f);
+  const float eps = rel * sqrtf(ss) * (row_norm_max * x_scale) + 1.125f * (float)d * 5.9604645e-8f;
+  const bool bad = nan || !(amax <= FLT_MAX) || !(eps == eps) || e + x_exp > 100 || e + x_exp < -100;
+  const float* v = vals + (size_t)q * kc1;
+  bool raise = bad;
+  if (!bad && n_tiles >= kc1) {  // fewer tiles than candidates: every tile is one already
+    const float Tk = v[k - 1], last = v[kc1 - 1];
+    raise = !(last < Tk - 2.f * eps);
+  }
+  if (raise) {
+    atomicOr(flag, 1);
+    atomicAdd(unresolved, 1u);  // amdr_dense_hi_counters
+  }
+}
+
+// (d = 1 024: the 128-KiB query tile + the stages would take all 160 KiB of LDS and the kernel all 256 VGPRs: not built)
+bool dense_hi_supported(int d) { return d >= 128 && d <= 896 && d % 128 == 0; }
+
+size_t dense_hi_lds(int d) { return (size_t)64 * d * 2 + kHiWaves * kHiStageBytes; }
+
+template <int D64>
+static int launch_hi(const float* X, long n, const float* Q, int nq, int grid, float* MT, float x_scale, hipStream_t st) {
+  AMDR_HIP(hipFuncSetAttribute((const void*)dense_hi_tilemax_kernel<D64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)dense_hi_lds(D64 * 64)));
+  hipLaunchKernelGGL((dense_hi_tilemax_kernel<D64>), dim3(grid), dim3(kHiWaves * 64), dense_hi_lds(D64 * 64), st, X, n, Q, nq,
+                     MT, hi_mt_cols(nq), x_scale);
+  AMDR_HIP(hipGetLastError());
+  return AMDR_OK;
+}
+
+size_t dense_hi_mt_bytes(long n) { return (size_t)((n + 31) / 32) * 64 * sizeof(float); }
+
+// approximate tile maxima of <= 64 queries: the scan writes MT[tile][64] (dense_hi_mt_bytes), the transposition M[q][tile]
+int dense_hi_launch_tilemax(const float* X, long n, int d, const float* Q, int nq, float* MT, hipStream_t st, float x_scale) {
+  if (!dense_hi_supported(d) || nq < 1 || nq > 64) return fail(AMDR_EINVAL, "dense (fp16 first pass): d=%d nq=%d", d, nq);
+  // one persistent block per CU (the query tile fills most of its LDS)
+  int dev = 0, cus = 256;
+  AMDR_HIP(hipGetDevice(&dev));
+  AMDR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const long tiles = (n + 31) / 32;
+  long blocks = (tiles + kHiWaves - 1) / kHiWaves;
+  if (blocks > cus) blocks = cus;
+  if (blocks < 1) blocks = 1;
+  const int grid = (int)blocks;
+  switch (d / 64) {
+    case 2: return launch_hi<2>(X, n, Q, nq, grid, MT, x_scale, st);
+    case 4: return launch_hi<4>(X, n, Q, nq, grid, MT, x_scale, st);
+    case 6: return launch_hi<6>(X, n, Q, nq, grid, MT, x_scale, st);
+    case 8: return launch_hi<8>(X, n, Q, nq, grid, MT, x_scale, st);
+    case 10: return launch_hi<10>(X, n, Q, nq, grid, MT, x_scale, st);
+    case 12: return launch_hi<12>(X, n, Q, nq, grid, MT, x_scale, st);
+    case 14: return launch_hi<14>(X, n, Q, nq, grid, MT, x_scale, st);
+    default: return fail(AMDR_EINVAL, "dense (fp16 first pass): unsupported dim %d", d);
+  }
+}
+
+int dense_hi_launch_transpose(const float* MT, long n, int nq, long ldM, float* M, hipStream_t st) {
+  const long tiles = (n + 31) / 32;
+  hipLaunchKernelGGL(dense_hi_transpose_kernel, dim3((unsigned)((tiles + kHiTrTiles - 1) / kHiTrTiles)), dim3(256), 0, st, MT,
+                     tiles, nq, ldM, M);
+  AMDR_HIP(hipGetLastError());
+  return AMDR_OK;
+}
+
+int dense_hi_launch_check(const float* vals, int m, int kc1, int k, const float* Q, int d, float row_norm_max, float x_scale,
+                          long n_tiles, int* flag, unsigned int* unresolved, hipStream_t st) {
+  int x_exp = 0;
+  (void)frexpf(x_scale, &x_exp);  // x_scale = 2^-ex = 0.5 * 2^(1 - ex)
+  x_exp = 1 - x_exp;
+  hipLaunchKernelGGL(dense_hi_check_kernel, dim3(m), dim3(64), 0, st, vals, kc1, k, Q, d, row_norm_max, x_scale, x_exp, n_tiles,
+                     flag, unresolved);
+  AMDR_HIP(hipGetLastError());
+  return AMDR_OK;
+}
+
+// max |component| and max row norm of X[row0 .. row0 + n): out2 must hold two zeroed unsigned ints
+int dense_stats_launch(const float* X, long n, int d, unsigned int* out2, hipStream_t st) {
+  if (n <= 0) return AMDR_OK;
+  hipLaunchKernelGGL(dense_stats_kernel, dim3(2048), dim3(256), 0, st, X, n, d, out2);
+  AMDR_HIP(hipGetLastError());
+  return AMDR_OK;
+}
+
+}  // namespace amdr

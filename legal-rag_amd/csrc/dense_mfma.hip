@@ -114,7 +114,9 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
                                                                  long rows_per_block, int gx, int gy, long ldS,
                                                                  float* __restrict__ S /*[queries][ldS]*/, int mode,
                                                                  const int* __restrict__ tile_list,
-                                                                 const int* __restrict__ tile_count, long n_real) {
+                                                                 const int* __restrict__ tile_count, long n_real,
+                                                                 const int* __restrict__ gate) {
+  if (gate != nullptr && *gate == 0) return;  // a gated launch (dense_hi.hip): decided on the device, block-uniform
   // mode 0: S[query][row] for every row.
   // mode 1: S[query][tile] = MAXIMUM of the query's scores over the 32-row tile (first pass of the two-level
   //         top-k of a large scan: dense.hip run_search_two_level).
@@ -341,8 +343,10 @@ __global__ __launch_bounds__(WAVES * 64) void scores_slab_topk_kernel(const floa
                                                                        int cap, long rows_per_slab,
                                                                        C32* __restrict__ part,
                                                                        float* __restrict__ fin_scores,
-                                                                       long long* __restrict__ fin_ids) {
+                                                                       long long* __restrict__ fin_ids,
+                                                                       const int* __restrict__ gate) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (gate != nullptr && *gate == 0) return;
   C32* lists = reinterpret_cast<C32*>(smem);
   int* cnts = reinterpret_cast<int*>(lists + (size_t)WAVES * cap);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -409,8 +413,10 @@ __global__ __launch_bounds__(WAVES * 64) void scores_slab_topk_kernel(const floa
 
 __global__ __launch_bounds__(64) void scores_pair_topk_kernel(const float* __restrict__ S, long ldS, long n, int nq,
                                                               int k, int cap, float* __restrict__ fin_scores,
-                                                              long long* __restrict__ fin_ids) {
+                                                              long long* __restrict__ fin_ids,
+                                                              const int* __restrict__ gate) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (gate != nullptr && *gate == 0) return;
   C32* buf = reinterpret_cast<C32*>(smem);  // cap entries (>= 128): staged-selector list; the pair selector uses 64
   const int lane = threadIdx.x;
   const int q = 2 * blockIdx.x + (lane >> 5);
@@ -453,8 +459,10 @@ __global__ __launch_bounds__(64) void scores_pair_topk_kernel(const float* __res
 // list without duplicates + its length.  One wave; bitonic sort in LDS (descending on id + 1, so that "none" sorts
 // last), neighbour compare, one prefix sum.
 __global__ __launch_bounds__(64) void tiles_unique_kernel(const long long* __restrict__ tile_ids, int n_in, int cap,
-                                                          int* __restrict__ list, int* __restrict__ count) {
+                                                          int* __restrict__ list, int* __restrict__ count,
+                                                          const int* __restrict__ gate) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (gate != nullptr && *gate == 0) return;
   C32* buf = reinterpret_cast<C32*>(smem);
   const int lane = threadIdx.x;
   for (int i = lane; i < cap; i += 64) {
@@ -485,11 +493,65 @@ __global__ __launch_bounds__(64) void tiles_unique_kernel(const long long* __res
   if (lane == 0) *count = total;
 }
 
+// The same list from a bitmap of the tiles in LDS (one block of 1 024 threads, up to 2^20 tiles = 128 KiB of bits):
+// mark, popcount prefix sum over the words, emit ascending.  The one-wave sort above takes 0.3 ms for the 2 112
+// candidates of a 64-query pass behind the fp16 first pass — more than every other step after the scan together.
+constexpr int kUniqueBitmapTilesMax = 1 << 20;
+__global__ __launch_bounds__(1024) void tiles_unique_bitmap_kernel(const long long* __restrict__ tile_ids, int n_in,
+                                                                   int n_tiles, int* __restrict__ list,
+                                                                   int* __restrict__ count,
+                                                                   const int* __restrict__ gate) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (gate != nullptr && *gate == 0) return;
+  const int words = (n_tiles + 31) >> 5;
+  unsigned int* bm = reinterpret_cast<unsigned int*>(smem);
+  int* wsum = reinterpret_cast<int*>(bm + words);  // 16 wave totals
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < words; i += 1024) bm[i] = 0u;
+  __syncthreads();
+  for (int i = tid; i < n_in; i += 1024) {
+    const long long v = tile_ids[i];
+    if (v >= 0 && v < n_tiles) atomicOr(&bm[v >> 5], 1u << (v & 31));
+  }
+  __syncthreads();
+  const int per = (words + 1023) / 1024, w0 = tid * per;
+  int mine = 0;
+  for (int j = 0; j < per; ++j)
+    if (w0 + j < words) mine += __popc(bm[w0 + j]);
+  int incl = mine;
+#pragma unroll
+  for (int s2 = 1; s2 < 64; s2 <<= 1) {
+    const int o = __shfl_up(incl, s2);
+    incl += (lane >= s2) ? o : 0;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int base = 0, total = 0;
+  for (int w = 0; w < 16; ++w) {
+    const int x = wsum[w];
+    base += w < wave ? x : 0;
+    total += x;
+  }
+  int pos = base + incl - mine;
+  for (int j = 0; j < per; ++j) {
+    if (w0 + j >= words) break;
+    unsigned int x = bm[w0 + j];
+    while (x) {
+      const int b = __ffs((int)x) - 1;
+      list[pos++] = (w0 + j) * 32 + b;
+      x &= x - 1;
+    }
+  }
+  if (tid == 0) *count = total;
+}
+
 // step 4: the final hits carry COLUMNS of the re-scored candidate matrix (32 per list entry); columns ascend with the
 // row ids (the list is ascending), so ties were already broken towards the lower id.
 __global__ __launch_bounds__(256) void tiles_remap_ids_kernel(long long* __restrict__ ids, int total,
                                                               const int* __restrict__ list,
-                                                              const int* __restrict__ count, long n_real) {
+                                                              const int* __restrict__ count, long n_real,
+                                                              const int* __restrict__ gate) {
+  if (gate != nullptr && *gate == 0) return;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < total) {
     const long long c = ids[i];
@@ -504,17 +566,28 @@ __global__ __launch_bounds__(256) void tiles_remap_ids_kernel(long long* __restr
   }
 }
 
-int dense_tiles_unique_launch(const int64_t* tile_ids, int n_in, int* list, int* count, hipStream_t st) {
+int dense_tiles_unique_launch(const int64_t* tile_ids, int n_in, long n_tiles, int* list, int* count, hipStream_t st,
+                              const int* gate) {
+  if (n_tiles > 0 && n_tiles <= kUniqueBitmapTilesMax && n_in >= 512) {
+    const size_t lds = (size_t)((n_tiles + 31) / 32) * 4 + 64;
+    AMDR_HIP(hipFuncSetAttribute((const void*)tiles_unique_bitmap_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 128 * 1024 + 64));
+    hipLaunchKernelGGL(tiles_unique_bitmap_kernel, dim3(1), dim3(1024), lds, st, (const long long*)tile_ids, n_in,
+                       (int)n_tiles, list, count, gate);
+    AMDR_HIP(hipGetLastError());
+    return AMDR_OK;
+  }
   int cap = 64;
   while (cap < n_in) cap <<= 1;
   hipLaunchKernelGGL(tiles_unique_kernel, dim3(1), dim3(64), (size_t)cap * sizeof(C32), st, (const long long*)tile_ids, n_in,
-                     cap, list, count);
+                     cap, list, count, gate);
   AMDR_HIP(hipGetLastError());
   return AMDR_OK;
 }
-int dense_tiles_remap_launch(int64_t* ids, int total, const int* list, const int* count, long n_real, hipStream_t st) {
+int dense_tiles_remap_launch(int64_t* ids, int total, const int* list, const int* count, long n_real, hipStream_t st,
+                             const int* gate) {
   hipLaunchKernelGGL(tiles_remap_ids_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, (long long*)ids, total, list,
-                     count, n_real);
+                     count, n_real, gate);
   AMDR_HIP(hipGetLastError());
   return AMDR_OK;
 }
@@ -580,7 +653,8 @@ void dense_mfma_plan(long n, int d, int nq, int k, DenseMfmaPlan* p) {
 
 template <int D8, int WAVES, bool NTL>
 static int launch_scores(const DenseMfmaPlan& p, const float* X, long n, const float* Q, int nq, float* S,
-                         hipStream_t st, int mode, const int* tile_list, const int* tile_count, long n_real) {
+                         hipStream_t st, int mode, const int* tile_list, const int* tile_count, long n_real,
+                         const int* gate) {
   // 128-160 KiB of dynamic LDS needs the opt-in.  The attribute belongs to the (function, device)
   // pair, the C ABI takes a device ordinal, and setting it is cheap: set on every launch for the
   // current device rather than remembering "done" per process.
@@ -589,19 +663,20 @@ static int launch_scores(const DenseMfmaPlan& p, const float* X, long n, const f
                                D8 * 8 * 32 * (int)sizeof(float) + WAVES * kStageBufs * kStageBytes));
   hipLaunchKernelGGL((dense_mfma_scores_kernel<D8, WAVES, NTL>), dim3(p.grid_x * p.grid_y), dim3(WAVES * 64),
                      p.lds_scores, st, X, n, Q, nq, p.rows_per_block, p.grid_x, p.grid_y, p.ld, S, mode, tile_list, tile_count,
-                     n_real);
+                     n_real, gate);
   return AMDR_OK;
 }
 
 int dense_mfma_launch_scores(const DenseMfmaPlan& p, const float* X, long n, int d, const float* Q, int nq, float* S,
-                             hipStream_t st, int mode, const int* tile_list, const int* tile_count, long n_real) {
+                             hipStream_t st, int mode, const int* tile_list, const int* tile_count, long n_real,
+                             const int* gate) {
   int rc = AMDR_OK;
   const bool nt = dense_stream_nontemporal(mode == 2 ? n_real : n, d) && mode != 2;  // candidate tiles are re-read: cacheable
   switch (d) {
 #define AMDR_CASE(D)                                                          \
   case D:                                                                     \
-    rc = nt ? launch_scores<D / 8, scores_waves(D), true>(p, X, n, Q, nq, S, st, mode, tile_list, tile_count, n_real)   \
-            : launch_scores<D / 8, scores_waves(D), false>(p, X, n, Q, nq, S, st, mode, tile_list, tile_count, n_real); \
+    rc = nt ? launch_scores<D / 8, scores_waves(D), true>(p, X, n, Q, nq, S, st, mode, tile_list, tile_count, n_real, gate)   \
+            : launch_scores<D / 8, scores_waves(D), false>(p, X, n, Q, nq, S, st, mode, tile_list, tile_count, n_real, gate); \
     break;
     AMDR_CASE(64) AMDR_CASE(128) AMDR_CASE(192) AMDR_CASE(256) AMDR_CASE(320) AMDR_CASE(384)
     AMDR_CASE(448) AMDR_CASE(512) AMDR_CASE(576) AMDR_CASE(640) AMDR_CASE(704) AMDR_CASE(768)
@@ -615,23 +690,23 @@ int dense_mfma_launch_scores(const DenseMfmaPlan& p, const float* X, long n, int
 }
 
 int dense_mfma_launch_topk(const DenseMfmaPlan& p, const float* S, long n, int nq, int k, void* part,
-                           float* fin_scores, int64_t* fin_ids, hipStream_t st) {
+                           float* fin_scores, int64_t* fin_ids, hipStream_t st, const int* gate) {
   const int waves = p.rows_per_slab <= kSelectRowsMax ? 1 : kBW;
   size_t lds = (size_t)waves * p.cap * sizeof(C32) + waves * sizeof(int);
   const char* pair_env = getenv("AMDR_TOPK_PAIR");  // "0" pins one query per wave (A/B, tests)
   const bool pair_off = pair_env && pair_env[0] == '0';
   if (fin_ids && p.slabs == 1 && n <= 1024 && k <= 32 && nq >= 2 && !pair_off) {
     hipLaunchKernelGGL(scores_pair_topk_kernel, dim3((nq + 1) / 2), dim3(64), (size_t)p.cap * sizeof(C32), st, S, p.ld,
-                       n, nq, k, p.cap, fin_scores, (long long*)fin_ids);
+                       n, nq, k, p.cap, fin_scores, (long long*)fin_ids, gate);
     AMDR_HIP(hipGetLastError());
     return AMDR_OK;
   }
   if (waves == 1)
     hipLaunchKernelGGL(scores_slab_topk_kernel<1>, dim3(p.slabs, nq), dim3(64), lds, st, S, p.ld, n, nq, k, p.cap,
-                       p.rows_per_slab, (C32*)part, fin_scores, (long long*)fin_ids);
+                       p.rows_per_slab, (C32*)part, fin_scores, (long long*)fin_ids, gate);
   else
     hipLaunchKernelGGL(scores_slab_topk_kernel<kBW>, dim3(p.slabs, nq), dim3(256), lds, st, S, p.ld, n, nq, k, p.cap,
-                       p.rows_per_slab, (C32*)part, fin_scores, (long long*)fin_ids);
+                       p.rows_per_slab, (C32*)part, fin_scores, (long long*)fin_ids, gate);
   AMDR_HIP(hipGetLastError());
   return AMDR_OK;
 }

@@ -104,5 +104,15 @@ def test_dense_workspace_covers_every_pass(monkeypatch):
     assert checked > 300 and two_level > 50
     # the advisor's worked example, pinned: remainder 89 needs more list space than the chunk of 96
     monkeypatch.setenv("AMDR_DENSE_TWO_LEVEL", "1")
+    monkeypatch.setenv("AMDR_DENSE_HI", "0")  # the exact first pass (32-query tiles, chunks of 96)
     res, used = _native.dense_workspace_plan(13_000_000, 768, 185, 10)
     assert used[1] == 170880 and res[1] >= used[1]
+    # the fp16 first pass (chunks of 64, k + 23 candidate tiles per query) and the exact chain behind its flag
+    for hi in ("0", "1"):
+        monkeypatch.setenv("AMDR_DENSE_HI", hi)
+        for n in (13_000_000, 600_000, 40_000):
+            for d in (128, 384, 768, 896, 1024):
+                for k in (1, 10, 80, 127, 128):
+                    for nq in (5, 37, 64, 65, 100, 129):
+                        res, used = _native.dense_workspace_plan(n, d, nq, k)
+                        assert all(u <= r for u, r in zip(used, res)), (hi, n, d, k, nq, res, used)

@@ -1,0 +1,198 @@
+"""The fp16 first pass of the large-scan two-level top-k (csrc/dense_hi.hip, dense.hip run_search_two_level).
+
+AMDR_DENSE_HI=1 pins it on small matrices (with AMDR_DENSE_TWO_LEVEL unset or 1); it must return the ids and the
+score BITS of the exact two-level form (AMDR_DENSE_HI=0, AMDR_DENSE_TWO_LEVEL=1) and of the full score matrix
+(AMDR_DENSE_TWO_LEVEL=0): the first pass only picks candidate tiles, the scores come from the exact fp32 kernel.
+Cases: every supported width, ragged last tile, 5..130 queries (chunks of 64 + remainder), k = 1..80, matrices whose
+cut the rounding bound cannot separate (repeated rows, near-duplicates: the exact chain behind the device flag must
+take over), extreme scales of matrix and queries, NaN rows, add() after creation."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from legal_rag_amd import _native
+    _native.load()
+    return _native
+
+
+def unit_rows(rng, n, d):
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x
+
+
+def three_forms(nat, monkeypatch, X, Q, k, build=None):
+    """(hi, exact two-level, full) results + the hi handle's counters"""
+    out = {}
+    for name, hi, tl in (("hi", "1", "1"), ("exact", "0", "1"), ("full", "0", "0")):
+        monkeypatch.setenv("AMDR_DENSE_HI", hi)
+        monkeypatch.setenv("AMDR_DENSE_TWO_LEVEL", tl)
+        idx = build() if build else nat.DenseIndex(X)
+        if name == "hi":
+            assert "dense_hi_tilemax_kernel" in idx.plan_info(len(Q), k), idx.plan_info(len(Q), k)
+        else:
+            assert "dense_hi" not in idx.plan_info(len(Q), k)
+        out[name] = idx.search(Q, k)
+        if name == "hi":
+            out["counters"] = idx.hi_counters()
+        idx.close()
+    return out
+
+
+def assert_same(out, what):
+    for other in ("exact", "full"):
+        assert np.array_equal(out["hi"][1], out[other][1]), (what, other)
+        assert np.array_equal(out["hi"][0].view(np.uint32), out[other][0].view(np.uint32)), (what, other)
+
+
+def test_hi_first_pass_same_ids_and_bits(nat, monkeypatch):
+    rng = np.random.default_rng(2024)
+    cases = [(9017, 128, 64, 10), (9000, 256, 5, 1), (7777, 384, 33, 10), (9017, 768, 70, 10), (8200, 896, 130, 3),
+             (12017, 512, 64, 80), (30011, 128, 129, 40), (4100, 640, 17, 10)]
+    unresolved = 0
+    for n, d, nq, k in cases:
+        X, Q = unit_rows(rng, n, d), unit_rows(rng, nq, d)
+        out = three_forms(nat, monkeypatch, X, Q, k)
+        assert_same(out, (n, d, nq, k))
+        took, bad = out["counters"]
+        assert took == nq
+        unresolved += bad
+    # random unit rows: the bound separates (almost) every cut — the fast path is what ran
+    assert unresolved <= 2, unresolved
+
+
+def test_hi_first_pass_unsupported_shapes_take_the_exact_form(nat, monkeypatch):
+    rng = np.random.default_rng(5)
+    monkeypatch.setenv("AMDR_DENSE_HI", "1")
+    monkeypatch.setenv("AMDR_DENSE_TWO_LEVEL", "1")
+    for n, d, nq, k in ((9000, 1024, 33, 10), (9000, 192, 33, 10), (9000, 768, 4, 10), (9000, 768, 33, 128),
+                        (1200, 768, 33, 10)):
+        idx = nat.DenseIndex(unit_rows(rng, n, d))
+        assert "dense_hi" not in idx.plan_info(nq, k), (n, d, nq, k)
+        idx.close()
+
+
+def test_hi_first_pass_unresolvable_cuts_fall_back_on_the_device(nat, monkeypatch):
+    """Repeated rows / near-duplicates: more than k + 22 tiles lie within the rounding bound of the cut, the check
+    raises the flag and the gated exact chain rewrites the batch — same ids (lower id first among ties), same bits."""
+    rng = np.random.default_rng(77)
+    base = unit_rows(rng, 300, 256)
+    X = np.concatenate([base] * 40, axis=0)  # every row 40 times, 300 apart: 40 tiles tie at every rank
+    Q = unit_rows(rng, 70, 256)
+    out = three_forms(nat, monkeypatch, X, Q, 10)
+    assert_same(out, "repeated rows")
+    took, bad = out["counters"]
+    assert took == 70 and bad == 70
+    s, i = out["hi"]
+    ref = (base.astype(np.float64) @ Q.astype(np.float64).T).T
+    for b in range(70):
+        top = int(np.argmax(ref[b]))
+        assert i[b].tolist() == [top + 300 * j for j in range(10)]
+    # near-duplicates: 2 000 rows within 1e-4 of one direction, the rest random
+    v = unit_rows(rng, 1, 384)
+    near = v + 1e-4 * rng.standard_normal((2000, 384)).astype(np.float32)
+    X = unit_rows(rng, 12000, 384)
+    pos = rng.choice(12000, size=2000, replace=False)
+    X[pos] = near
+    Q = np.concatenate([v + 0.05 * unit_rows(rng, 20, 384), unit_rows(rng, 20, 384)])
+    out = three_forms(nat, monkeypatch, X, Q, 10)
+    assert_same(out, "near duplicates")
+    assert out["counters"][1] >= 20  # the 20 queries aimed at the cluster cannot be resolved by the fp16 pass
+    assert set(out["hi"][1][:20].ravel().tolist()) <= set(pos.tolist())
+
+
+def test_hi_first_pass_scales(nat, monkeypatch):
+    """Matrix and queries far from unit scale (power-of-two scaling inside the pass, the bound scales with both)."""
+    rng = np.random.default_rng(8)
+    for xs, qs in ((1e-18, 1.0), (3e9, 1e-7), (1.0, 5e12), (7e-4, 2e-30)):
+        X = (unit_rows(rng, 9017, 256) * np.float32(xs)).astype(np.float32)
+        Q = (unit_rows(rng, 40, 256) * np.float32(qs)).astype(np.float32)
+        Q[3] *= np.float32(1e-6)  # per-query scale
+        Q[7] = 0                  # all scores equal: lowest ids win, through the fallback
+        out = three_forms(nat, monkeypatch, X, Q, 10)
+        assert_same(out, (xs, qs))
+        assert out["hi"][1][7].tolist() == list(range(10))
+    # rows of very different norms: the largest norm drives the bound
+    X = unit_rows(rng, 9017, 128) * rng.uniform(0.01, 30.0, size=(9017, 1)).astype(np.float32)
+    out = three_forms(nat, monkeypatch, X.astype(np.float32), unit_rows(rng, 64, 128), 10)
+    assert_same(out, "mixed norms")
+
+
+def test_hi_first_pass_nan_rows_and_nan_queries(nat, monkeypatch):
+    rng = np.random.default_rng(19)
+    X, Q = unit_rows(rng, 9017, 128), unit_rows(rng, 33, 128)
+    X[::7] = np.nan
+    out = three_forms(nat, monkeypatch, X, Q, 10)
+    assert_same(out, "nan rows")
+    assert not np.isnan(out["hi"][0]).any() and not (out["hi"][1] % 7 == 0).any()
+    Xc = unit_rows(rng, 9017, 128)
+    Q[5, 3] = np.nan
+    Q[6, 0] = np.inf
+    monkeypatch.setenv("AMDR_DENSE_HI", "1")
+    monkeypatch.setenv("AMDR_DENSE_TWO_LEVEL", "1")
+    idx = nat.DenseIndex(Xc)
+    hi = idx.search(Q, 10)
+    idx.close()
+    monkeypatch.setenv("AMDR_DENSE_HI", "0")
+    idx = nat.DenseIndex(Xc)
+    ex = idx.search(Q, 10)
+    idx.close()
+    assert np.array_equal(hi[1], ex[1])  # the exact two-level form decides what a NaN / infinite query returns
+    assert np.array_equal(hi[0].view(np.uint32), ex[0].view(np.uint32))
+    # an infinite component in the matrix: the statistics are not finite, the pass is not taken at all
+    Xi = Xc.copy()
+    Xi[100, 5] = np.inf
+    monkeypatch.setenv("AMDR_DENSE_HI", "1")
+    idx = nat.DenseIndex(Xi)
+    assert "dense_hi" not in idx.plan_info(33, 10)
+    idx.close()
+
+
+def test_hi_first_pass_after_add(nat, monkeypatch):
+    """add() folds the new rows into the statistics (a larger component changes the scale, a larger norm the bound)."""
+    rng = np.random.default_rng(23)
+    A, B = unit_rows(rng, 6000, 256), unit_rows(rng, 3017, 256) * np.float32(40.0)
+    Q = unit_rows(rng, 64, 256)
+
+    def build():
+        idx = nat.DenseIndex(A)
+        idx.add(B)
+        return idx
+    out = three_forms(nat, monkeypatch, None, Q, 10, build=build)
+    assert_same(out, "add")
+    assert (out["hi"][1] >= 6000).all()  # the long rows win
+    one = three_forms(nat, monkeypatch, np.concatenate([A, B]), Q, 10)
+    assert np.array_equal(one["hi"][1], out["hi"][1]) and np.array_equal(one["hi"][0], out["hi"][0])
+
+
+def test_hi_first_pass_device_entry_and_reserve(nat, monkeypatch):
+    """The `_device` entry (caller's stream, no host round trip inside) after reserve(): no allocation during the
+    search, same results as the host entry."""
+    import torch
+    rng = np.random.default_rng(29)
+    monkeypatch.setenv("AMDR_DENSE_HI", "1")
+    X, Q = unit_rows(rng, 9017, 384), unit_rows(rng, 100, 384)
+    idx = nat.DenseIndex(X)
+    ref = idx.search(Q, 10)
+    idx.reserve(100, 10)
+    Qd = torch.from_numpy(Q).cuda()
+    s = torch.empty(100, 10, dtype=torch.float32, device="cuda")
+    i = torch.empty(100, 10, dtype=torch.int64, device="cuda")
+    free0 = torch.cuda.mem_get_info()[0]
+    for nq in (100, 64, 37, 5):
+        idx.search_device(Qd[:nq].data_ptr(), nq, 10, s.data_ptr(), i.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(i[:nq].cpu().numpy(), ref[1][:nq])
+        assert np.array_equal(s[:nq].cpu().numpy(), ref[0][:nq])
+    assert torch.cuda.mem_get_info()[0] == free0
+    idx.close()
