@@ -95,10 +95,14 @@ int amdr_dense_workspace_plan(int64_t n, int32_t d, int32_t nq, int32_t k, int64
  * fp16 matrix instructions over fp16 roundings of both operands, 64 queries per scan; its candidate cut is widened by a
  * proven rounding bound and the second pass is the exact fp32 kernel, so ids and score bits are those of the exact
  * forms (csrc/dense_hi.hip).  A query whose cut the bound does not separate sends its batch through the exact first
- * pass as well (decided on the device).  out2[0] = queries that took the fp16 first pass since creation, out2[1] =
- * those it could not resolve.  Synchronises the device.  The matrix wrapped by amdr_dense_create_from_device must not
- * change while the handle lives (its largest component and row norm are measured at creation). */
-int amdr_dense_hi_counters(amdr_dense_t* h, int64_t* out2);
+ * pass as well (decided on the device).  The width of the candidate cut adapts per handle: k + max(k, 22 / 54 / 96)
+ * + 1 tiles per query (levels 0-2); a handle that sees more than 10 % of >= 256 queries unresolved moves up a level,
+ * at the top level more than 25 % make it give the fp16 pass up (exact passes from then on); AMDR_DENSE_HI_LEVEL pins
+ * the level.  out4[0] = queries that took the fp16 first pass since creation, out4[1] = those it could not resolve,
+ * out4[2] = current level, out4[3] = 1 while the pass is in use.  Synchronises the device.  The matrix wrapped by
+ * amdr_dense_create_from_device must not change while the handle lives (its largest component and row norm are
+ * measured at creation). */
+int amdr_dense_hi_counters(amdr_dense_t* h, int64_t* out4);
 /* HIP-event bracket around the scan kernel alone (not the merge), recorded on
  * the stream each search is launched on; used by bench.py for the roofline.
  * begin() arms up to max_launches event pairs, end() returns the summed scan

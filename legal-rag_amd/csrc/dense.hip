@@ -315,6 +315,13 @@ struct amdr_dense {
   float row_norm_max = 0.f;  // largest row L2 norm
   bool hi_ok = false;        // d supported and both statistics finite
   int64_t hi_queries = 0;    // queries that went through the fp16 first pass (amdr_dense_hi_counters)
+  // adaptive width of the candidate cut: level l re-scores k + max(k, kHiExtra[l]) + 1 tiles per query; a handle whose
+  // queries the rounding bound keeps failing to resolve moves up a level, and at the top level gives the pass up
+  int hi_level = 0;
+  bool hi_off = false;
+  int64_t lvl_q0 = 0;           // hi_queries / unresolved counter when the current level was entered
+  unsigned int lvl_u0 = 0;
+  unsigned int* hi_host = nullptr;  // pinned: the device's unresolved-query counter, copied back after every pass
   // optional HIP-event ring bracketing the scan kernel alone (bench.py roofline)
   std::vector<hipEvent_t> prof_ev;
   int prof_used = 0;
@@ -513,23 +520,55 @@ int two_level_chunk(int nq, int k) {
 // and a tile holding a row >= s_k has a(t) >= s_k - eps >= T_k - 2 eps — it is among the first kc - 1.  Steps 3-4 are
 // the unchanged exact kernels: same ids, same score bits.  A query the bound does not separate raises a device flag;
 // the exact chain is enqueued behind, every launch gated on that flag (no host round trip), and rewrites the batch.
-// extra candidates: the tiles expected within 2 eps below the cut grow with k (about 0.4 k on unit-norm Gaussian rows)
-int hi_kc(int k) { return k + (k > 22 ? k : 22) + 1; }
+// Extra candidates: the tiles expected within 2 eps below the cut grow with k (about 0.4 k on unit-norm Gaussian rows)
+// and with how tightly the matrix clusters around a query's best rows, which only the data knows: three widths.
+constexpr int kHiLevels = 3;
+constexpr int kHiExtra[kHiLevels] = {22, 54, 96};
+int hi_kc(int k, int level) { return k + (k > kHiExtra[level] ? k : kHiExtra[level]) + 1; }
+int hi_kc_max(int k) { return hi_kc(k, kHiLevels - 1); }
+int hi_level_of(const amdr_dense* h) {
+  const char* e = getenv("AMDR_DENSE_HI_LEVEL");  // pins the width (tests, A/B)
+  if (e && e[0] >= '0' && e[0] < '0' + kHiLevels) return e[0] - '0';
+  return h->hi_level;
+}
 bool hi_applies(const amdr_dense* h, int nq, int k) {
   const char* e = getenv("AMDR_DENSE_HI");
   if (e && e[0] == '0') return false;
   const char* e2 = getenv("AMDR_DENSE_TWO_LEVEL");
   if (e2 && e2[0] == '0') return false;
   if (!(h->hi_ok && nq >= kBatchedMin && h->n > 0 && dense_mfma_supported(h->d))) return false;
-  if (hi_kc(k) > AMDR_MAX_K) return false;
+  if (hi_kc_max(k) > AMDR_MAX_K) return false;  // k <= 127
   const long tiles = ((long)h->n + 31) / 32;
-  if (e && e[0] == '1') return tiles >= 2L * hi_kc(k);  // pinned on (tests)
-  return dense_stream_nontemporal((long)h->n, h->d) && tiles >= 64L * hi_kc(k);
+  if (e && e[0] == '1') return tiles >= 2L * hi_kc_max(k);  // pinned on (tests)
+  return dense_stream_nontemporal((long)h->n, h->d) && tiles >= 64L * hi_kc_max(k);
 }
-int hi_chunk(int nq, int k) {
-  int c = kTwoLevelTilesMax / hi_kc(k);  // >= 32 for every admitted k
-  if (c > 64) c = 64;
+int hi_chunk(const amdr_dense* h, int nq, int k) {  // the same at every level: a handle's passes keep their shape when its level moves
+  int c = 64;
+  // the candidate union is a bitmap over the tiles (any number of candidates) up to 2^20 tiles; beyond, the one-wave sort
+  // and its 8 192-candidate limit (>= 32 queries for every admitted k)
+  if (((long)h->n + 31) / 32 > kUniqueBitmapTilesMax && kTwoLevelTilesMax / hi_kc_max(k) < c) c = kTwoLevelTilesMax / hi_kc_max(k);
   return nq < c ? nq : c;
+}
+// Between searches (host side, no synchronisation: the counter is whatever the last completed copy-back left).
+void hi_adapt(amdr_dense* h) {
+  if (!h->hi_host || h->hi_off || getenv("AMDR_DENSE_HI_LEVEL")) return;
+  const unsigned int u = *(volatile unsigned int*)h->hi_host;
+  const int64_t q = h->hi_queries - h->lvl_q0;
+  const int64_t bad = (int64_t)(u - h->lvl_u0);
+  if (q < 256) return;
+  bool move = false;
+  if (h->hi_level + 1 < kHiLevels) {
+    move = bad * 10 > q;  // > 10 % of the level's queries went through the exact chain as well
+    if (move) ++h->hi_level;
+  } else {
+    const char* e = getenv("AMDR_DENSE_HI");
+    move = bad * 4 > q && !(e && e[0] == '1');  // top level, > 25 %: this matrix is not for the fp16 pass
+    if (move) h->hi_off = true;
+  }
+  if (move || q >= (1 << 20)) {  // a new window
+    h->lvl_q0 = h->hi_queries;
+    h->lvl_u0 = u;
+  }
 }
 
 struct TwoLevelPlan {
@@ -537,7 +576,7 @@ struct TwoLevelPlan {
   long tiles, cand_rows;
   size_t m_bytes, s2_bytes, aux_bytes, part_bytes;
 };
-// kc = candidate tiles per query: k in the exact form, hi_kc(k) behind the fp16 first pass
+// kc = candidate tiles per query: k in the exact form, hi_kc(k, level) behind the fp16 first pass
 void two_level_plan(const amdr_dense* h, int m, int k, int kc, TwoLevelPlan* t) {
   t->tiles = ((long)h->n + 31) / 32;
   dense_mfma_plan((long)h->n, h->d, m, k, &t->scan);
@@ -575,12 +614,14 @@ void two_level_need_exact(const amdr_dense* h, int nq, int k, TwoLevelNeed* need
 }
 void two_level_need(const amdr_dense* h, int nq, int k, TwoLevelNeed* need) {
   if (!hi_applies(h, nq, k)) return two_level_need_exact(h, nq, k, need);
-  const int chunk = hi_chunk(nq, k);
+  const int chunk = hi_chunk(h, nq, k);
   TwoLevelPlan t;
   for (int m : {chunk, nq % chunk}) {
     if (m == 0) continue;
-    two_level_plan(h, m, k, hi_kc(k), &t);
-    need->add(t);
+    for (int l = 0; l < kHiLevels; ++l) {  // the level can move between searches: reserve for all three
+      two_level_plan(h, m, k, hi_kc(k, l), &t);
+      need->add(t);
+    }
     two_level_need_exact(h, m, k, need);  // the gated exact chain of the same pass
   }
 }
@@ -596,10 +637,11 @@ int two_level_ensure(amdr_dense* h, int ws, int nq, int k, bool all = false) {
       if (!hi && !two_level_applies(h, nq < 95 ? nq : 95, kk) && !two_level_applies(h, nq, kk)) continue;
       TwoLevelPlan t;
       if (hi)
-        for (int m = 1; m <= hi_chunk(nq, kk); ++m) {
-          two_level_plan(h, m, kk, hi_kc(kk), &t);
-          need.add(t);
-        }
+        for (int m = 1; m <= hi_chunk(h, nq, kk); ++m)
+          for (int l = 0; l < kHiLevels; ++l) {
+            two_level_plan(h, m, kk, hi_kc(kk, l), &t);
+            need.add(t);
+          }
       const int cmax = two_level_chunk(nq, kk);
       for (int m = 1; m <= cmax; ++m) {
         two_level_plan(h, m, kk, kk, &t);
@@ -629,11 +671,12 @@ int topk_pass(const DenseMfmaPlan& p, const float* S, long cols, int m, int k, D
   return AMDR_OK;
 }
 
-// One pass of <= chunk queries.  hi: the fp16 first pass with kc = hi_kc(k) candidates, its check raises *flag;
-// otherwise the exact first pass, every launch gated on *gate when given.
-int two_level_pass(amdr_dense* h, int ws, const float* Qc, int m, int k, bool hi, float* out_scores, int64_t* out_ids,
+// One pass of <= chunk queries.  kc_hi > 0: the fp16 first pass with kc_hi candidate tiles per query, its check raises
+// *flag; otherwise the exact first pass, every launch gated on *gate when given.
+int two_level_pass(amdr_dense* h, int ws, const float* Qc, int m, int k, int kc_hi, float* out_scores, int64_t* out_ids,
                    hipStream_t st, int* flag, const int* gate) {
-  const int kc = hi ? hi_kc(k) : k;
+  const bool hi = kc_hi > 0;
+  const int kc = hi ? kc_hi : k;
   TwoLevelPlan t;
   two_level_plan(h, m, k, kc, &t);
   float* M = h->smat[ws].as<float>();
@@ -684,7 +727,9 @@ int run_search_two_level(amdr_dense* h, int ws, const float* Q_dev, int nq, int 
   int rc = two_level_ensure(h, ws, nq, k);
   if (rc) return rc;
   const bool hi = hi_applies(h, nq, k);
-  const int chunk = hi ? hi_chunk(nq, k) : two_level_chunk(nq, k);
+  if (hi) hi_adapt(h);
+  const int chunk = hi ? hi_chunk(h, nq, k) : two_level_chunk(nq, k);
+  const int kc_hi = hi && !h->hi_off ? hi_kc(k, hi_level_of(h)) : 0;
   // the gate flag: behind the largest list layout of this call (two_level_ensure sized aux for it)
   int* flag = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(h->aux[ws].p) + h->aux[ws].cap - 256);
   for (int q0 = 0; q0 < nq; q0 += chunk) {
@@ -693,19 +738,25 @@ int run_search_two_level(amdr_dense* h, int ws, const float* Q_dev, int nq, int 
     float* os = scores_dev + (size_t)q0 * k;
     int64_t* oi = ids_dev + (size_t)q0 * k;
     if (!hi) {
-      if ((rc = two_level_pass(h, ws, Qc, m, k, false, os, oi, st, nullptr, nullptr))) return rc;
+      if ((rc = two_level_pass(h, ws, Qc, m, k, 0, os, oi, st, nullptr, nullptr))) return rc;
       continue;
     }
-    AMDR_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
-    if ((rc = two_level_pass(h, ws, Qc, m, k, true, os, oi, st, flag, nullptr))) return rc;
-    const int ec = two_level_chunk(m, k);  // the exact chain holds 32-query tiles
+    if (kc_hi) {
+      AMDR_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
+      if ((rc = two_level_pass(h, ws, Qc, m, k, kc_hi, os, oi, st, flag, nullptr))) return rc;
+    }
+    // the exact chain holds 32-query tiles; behind the fp16 pass it runs only if the flag was raised — and
+    // unconditionally, in the same pass shapes (same workspace), on a handle that gave the fp16 pass up
+    const int ec = two_level_chunk(m, k);
     for (int e0 = 0; e0 < m; e0 += ec) {
       const int em = m - e0 < ec ? m - e0 : ec;
-      if ((rc = two_level_pass(h, ws, Qc + (size_t)e0 * h->d, em, k, false, os + (size_t)e0 * k, oi + (size_t)e0 * k, st,
-                               nullptr, flag)))
+      if ((rc = two_level_pass(h, ws, Qc + (size_t)e0 * h->d, em, k, 0, os + (size_t)e0 * k, oi + (size_t)e0 * k, st,
+                               nullptr, kc_hi ? flag : nullptr)))
         return rc;
     }
   }
+  if (kc_hi && h->hi_host)  // what hi_adapt reads before the next search
+    AMDR_HIP(hipMemcpyAsync(h->hi_host, h->stats.as<unsigned int>() + 2, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
   return AMDR_OK;
 }
 
@@ -765,6 +816,10 @@ int update_stats(amdr_dense* h, int64_t row0, int64_t rows) {
   int rc = h->stats.ensure(4 * sizeof(unsigned int));  // max |x|, max row norm, unresolved queries (counter), pad
   if (rc) return rc;
   if (row0 == 0) AMDR_HIP(hipMemsetAsync(h->stats.p, 0, 4 * sizeof(unsigned int), h->stream));
+  if (!h->hi_host) {
+    AMDR_HIP(hipHostMalloc((void**)&h->hi_host, 4 * sizeof(unsigned int), hipHostMallocDefault));
+    h->hi_host[0] = 0u;
+  }
   if ((rc = dense_stats_launch(h->X + (size_t)row0 * h->d, (long)rows, h->d, h->stats.as<unsigned int>(), h->stream)))
     return rc;
   float st[2] = {0.f, 0.f};
@@ -1013,14 +1068,15 @@ int amdr_dense_workspace_plan(int64_t n, int32_t d, int32_t nq, int32_t k, int64
     two_level_need(&h, nq, k, &need);
     out6[0] = (int64_t)need.smat, out6[1] = (int64_t)need.part, out6[2] = (int64_t)need.aux;
     const bool hi = hi_applies(&h, nq, k);
-    const int chunk = hi ? hi_chunk(nq, k) : two_level_chunk(nq, k);
+    const int chunk = hi ? hi_chunk(&h, nq, k) : two_level_chunk(nq, k);
     for (int q0 = 0; q0 < nq; q0 += chunk) {  // what the pass loop of run_search_two_level touches
       const int m = nq - q0 < chunk ? nq - q0 : chunk;
       TwoLevelPlan t;
-      if (hi) {
-        two_level_plan(&h, m, k, hi_kc(k), &t);
-        used.add(t);
-      }
+      if (hi)
+        for (int l = 0; l < kHiLevels; ++l) {
+          two_level_plan(&h, m, k, hi_kc(k, l), &t);
+          used.add(t);
+        }
       const int ec = hi ? two_level_chunk(m, k) : m;
       for (int e0 = 0; e0 < m; e0 += ec) {
         two_level_plan(&h, m - e0 < ec ? m - e0 : ec, k, k, &t);
@@ -1048,15 +1104,25 @@ int amdr_dense_plan_info(const amdr_dense_t* h, int32_t nq, int32_t k, char* buf
     snprintf(buf, buf_len, "empty index");
     return AMDR_OK;
   }
-  if (hi_applies(h, nq, k)) {
+  if (hi_applies(h, nq, k) && !h->hi_off) {
     TwoLevelPlan t;
-    const int m = hi_chunk(nq, k);
-    two_level_plan(h, m, k, hi_kc(k), &t);
+    const int m = hi_chunk(h, nq, k), kc = hi_kc(k, hi_level_of(h));
+    two_level_plan(h, m, k, kc, &t);
     snprintf(buf, buf_len,
              "dense_hi_tilemax_kernel fp16 first pass queries_per_launch=%d two-level: top-%d of %ld approximate tile "
-             "maxima, cut checked against the rounding bound + exact re-scoring of <= %d candidate tiles + top-k "
-             "(exact first pass behind a device flag)",
-             m, hi_kc(k), t.tiles, m * hi_kc(k));
+             "maxima (width level %d), cut checked against the rounding bound + exact re-scoring of <= %d candidate tiles "
+             "+ top-k (exact first pass behind a device flag)",
+             m, kc, t.tiles, hi_level_of(h), m * kc);
+    return AMDR_OK;
+  }
+  if (hi_applies(h, nq, k)) {  // the handle gave the fp16 pass up: exact passes in the same shapes
+    TwoLevelPlan t;
+    const int m = two_level_chunk(hi_chunk(h, nq, k), k);
+    two_level_plan(h, m, k, k, &t);
+    snprintf(buf, buf_len,
+             "dense_mfma_scores_kernel tile-maxima grid=%dx%d queries_per_launch=%d two-level: top-%d of %ld tile maxima "
+             "+ re-scoring of <= %d candidate tiles + top-k (fp16 first pass given up: too many unresolved queries)",
+             t.scan.grid_x, t.scan.grid_y, m, k, t.tiles, m * k);
     return AMDR_OK;
   }
   if (two_level_applies(h, nq, k)) {
@@ -1095,8 +1161,9 @@ int amdr_dense_plan_info(const amdr_dense_t* h, int32_t nq, int32_t k, char* buf
   return AMDR_OK;
 }
 
-int amdr_dense_hi_counters(amdr_dense_t* h, int64_t* out2) {
-  AMDR_REQUIRE(h && out2, "dense_hi_counters: null");
+int amdr_dense_hi_counters(amdr_dense_t* h, int64_t* out4) {
+  int64_t* out2 = out4;
+  AMDR_REQUIRE(h && out4, "dense_hi_counters: null");
   std::lock_guard<std::mutex> g(h->mu);
   AMDR_HIP(hipSetDevice(h->device));
   out2[0] = h->hi_queries;
@@ -1107,6 +1174,8 @@ int amdr_dense_hi_counters(amdr_dense_t* h, int64_t* out2) {
     AMDR_HIP(hipMemcpy(&c, h->stats.as<unsigned int>() + 2, sizeof(c), hipMemcpyDeviceToHost));
     out2[1] = (int64_t)c;
   }
+  out4[2] = hi_level_of(h);
+  out4[3] = h->hi_ok && !h->hi_off ? 1 : 0;
   return AMDR_OK;
 }
 
@@ -1160,6 +1229,7 @@ int amdr_dense_destroy(amdr_dense_t* h) {
   h->sbuf.release();
   h->ibuf.release();
   h->stats.release();
+  if (h->hi_host) (void)hipHostFree(h->hi_host);
   delete h;
   return AMDR_OK;
 }

@@ -496,7 +496,6 @@ __global__ __launch_bounds__(64) void tiles_unique_kernel(const long long* __res
 // The same list from a bitmap of the tiles in LDS (one block of 1 024 threads, up to 2^20 tiles = 128 KiB of bits):
 // mark, popcount prefix sum over the words, emit ascending.  The one-wave sort above takes 0.3 ms for the 2 112
 // candidates of a 64-query pass behind the fp16 first pass — more than every other step after the scan together.
-constexpr int kUniqueBitmapTilesMax = 1 << 20;
 __global__ __launch_bounds__(1024) void tiles_unique_bitmap_kernel(const long long* __restrict__ tile_ids, int n_in,
                                                                    int n_tiles, int* __restrict__ list,
                                                                    int* __restrict__ count,

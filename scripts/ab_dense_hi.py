@@ -34,7 +34,7 @@ def run(X, Q, n, d, B, k, steps, hi):
     ms, launches = idx.profile_end()
     out = {"hi": hi, "B": B, "k": k, "plan": idx.plan_info(B, k)[:60], "scan_ms": ms / max(launches, 1),
            "launches_per_search": launches / steps, "wall_ms": wall * 1e3, "qps": B / wall,
-           "counters": idx.hi_counters()}
+           "counters": list(idx.hi_counters())}
     res = (s.cpu().numpy().copy(), i.cpu().numpy().copy())
     idx.close()
     return out, res
