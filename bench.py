@@ -632,11 +632,12 @@ def scan_algorithmic_bytes(plan, n, d, B, k):
     kernel = plan.split(" ")[0].split("<")[0]
     batched = kernel != "dense_scan_topk_kernel"  # scores S[B, n] are written once and read once
     two_level = "two-level" in plan  # the scan keeps one maximum per 32-row tile and query, not every score
-    hi = kernel == "dense_hi_tilemax_kernel"  # fp16 first pass: <= 64 queries per scan, maxima rows padded to 16 queries
+    hi = kernel == "dense_hi_tilemax_kernel"  # fp16 first pass: <= 64 queries per scan
     per_scan = int(plan.split("queries_per_launch=")[1].split()[0]) if "queries_per_launch=" in plan else B
-    cols = (per_scan + 15) // 16 * 16 if hi else per_scan
+    if hi:  # the scan emits only the maxima that reach the sample's threshold (~kc x stride per query): no per-tile output
+        return kernel, hi, per_scan, float(n) * d * 4 + per_scan * d * 4
     nbytes = float(n) * d * 4 + per_scan * d * 4 + (
-        (float(n) / 32 * cols * 4 if two_level else float(n) * per_scan * 4) if batched else B * k * 8)
+        (float(n) / 32 * per_scan * 4 if two_level else float(n) * per_scan * 4) if batched else B * k * 8)
     return kernel, hi, per_scan, nbytes
 
 

@@ -100,11 +100,20 @@ int dense_mfma_launch_topk(const DenseMfmaPlan& p, const float* S, long n, int n
 
 // ---- fp16 first pass of the two-level top-k on large matrices: dense_hi.hip ----
 bool dense_hi_supported(int d);
-size_t dense_hi_mt_bytes(long n);
-int dense_hi_launch_tilemax(const float* X, long n, int d, const float* Q, int nq, float* MT, hipStream_t st, float x_scale);
-int dense_hi_launch_transpose(const float* MT, long n, int nq, long ldM, float* M, hipStream_t st);
-int dense_hi_launch_check(const float* vals, int m, int kc1, int k, const float* Q, int d, float row_norm_max, float x_scale,
-                          long n_tiles, int* flag, unsigned int* unresolved, hipStream_t st);
+long dense_hi_sample_stride(long n);
+long dense_hi_sample_items(long n);
+size_t dense_hi_mt_bytes(long n);                       // maxima of the sample, [items][64]
+size_t dense_hi_cand_entries(long n, int m, int kc);    // 8-byte entries of the flat candidate list
+int dense_hi_launch_sample(const float* X, long n, int d, const float* Q, int nq, float* MT, hipStream_t st, float x_scale);
+int dense_hi_launch_transpose(const float* MT, long items, int nq, long ldM, float* M, hipStream_t st);
+int dense_hi_launch_emit(const float* X, long n, int d, const float* Q, int nq, const float* tau, int tau_stride, void* cand,
+                         unsigned int* total, size_t cap, hipStream_t st, float x_scale);
+size_t dense_hi_cand_part_bytes(int m, int kc);
+int dense_hi_launch_cand_topk(const void* cand, const unsigned int* total, size_t cap, int m, int kc, void* part,
+                              int* nparts, hipStream_t st);
+int dense_hi_launch_check(const float* vals, const int64_t* ids, int m, int kc1, int k, const float* Q, int d,
+                          float row_norm_max, float x_scale, long n_tiles, const unsigned int* total, size_t cap, int* flag,
+                          unsigned int* unresolved, hipStream_t st);
 int dense_stats_launch(const float* X, long n, int d, unsigned int* out2, hipStream_t st);
 
 

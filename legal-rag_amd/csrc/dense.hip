@@ -539,6 +539,7 @@ bool hi_applies(const amdr_dense* h, int nq, int k) {
   if (!(h->hi_ok && nq >= kBatchedMin && h->n > 0 && dense_mfma_supported(h->d))) return false;
   if (hi_kc_max(k) > AMDR_MAX_K) return false;  // k <= 127
   const long tiles = ((long)h->n + 31) / 32;
+  if (tiles >= (1l << 26)) return false;  // (query, tile) packed in 32 bits of a candidate entry
   if (e && e[0] == '1') return tiles >= 2L * hi_kc_max(k);  // pinned on (tests)
   return dense_stream_nontemporal((long)h->n, h->d) && tiles >= 64L * hi_kc_max(k);
 }
@@ -575,19 +576,28 @@ struct TwoLevelPlan {
   DenseMfmaPlan scan, tk1, pass2;  // full scan (mode 1), top-kc over the tile maxima, candidate re-scoring + its top-k
   long tiles, cand_rows;
   size_t m_bytes, s2_bytes, aux_bytes, part_bytes;
+  // fp16 first pass only: the sample (tk1 then ranks ITS maxima), the flat candidate list
+  long sample_items;
+  size_t s2_own, mt_bytes, cand_entries;
 };
 // kc = candidate tiles per query: k in the exact form, hi_kc(k, level) behind the fp16 first pass
 void two_level_plan(const amdr_dense* h, int m, int k, int kc, TwoLevelPlan* t) {
+  const bool hi = kc != k;
   t->tiles = ((long)h->n + 31) / 32;
+  t->sample_items = hi ? dense_hi_sample_items((long)h->n) : 0;
   dense_mfma_plan((long)h->n, h->d, m, k, &t->scan);
-  dense_mfma_plan(t->tiles, h->d, m, kc, &t->tk1);  // only its top-k half is used: columns = tiles
+  dense_mfma_plan(hi ? t->sample_items : t->tiles, h->d, m, kc, &t->tk1);  // only its top-k half is used: columns = tiles
   t->cand_rows = (long)m * kc * 32;
   dense_mfma_plan(t->cand_rows, h->d, m, k, &t->pass2);
   t->m_bytes = ((size_t)m * t->tk1.ld * sizeof(float) + 255) / 256 * 256;
-  t->s2_bytes = (size_t)m * t->pass2.ld * sizeof(float);
-  if (kc != k) t->s2_bytes = (t->s2_bytes + 255) / 256 * 256 + dense_hi_mt_bytes((long)h->n);  // + MT behind S2
-  t->aux_bytes = (size_t)m * kc * (sizeof(int64_t) + sizeof(float)) + (size_t)(m * kc + 64) * sizeof(int) + 256;
+  t->s2_own = ((size_t)m * t->pass2.ld * sizeof(float) + 255) / 256 * 256;
+  t->mt_bytes = hi ? (dense_hi_mt_bytes((long)h->n) + 255) / 256 * 256 : 0;
+  t->cand_entries = hi ? dense_hi_cand_entries((long)h->n, m, kc) : 0;
+  t->s2_bytes = t->s2_own + t->mt_bytes + t->cand_entries * sizeof(C32);  // S2 | sample maxima | candidate list
+  // tile ids + maxima, union list + count; behind the fp16 pass also the sample's top-kc (ids + maxima)
+  t->aux_bytes = (size_t)m * kc * (sizeof(int64_t) + sizeof(float)) * (hi ? 2 : 1) + (size_t)(m * kc + 64) * sizeof(int) + 256;
   t->part_bytes = t->tk1.part_bytes > t->pass2.part_bytes ? t->tk1.part_bytes : t->pass2.part_bytes;
+  if (hi && dense_hi_cand_part_bytes(m, kc) > t->part_bytes) t->part_bytes = dense_hi_cand_part_bytes(m, kc);
 }
 // Workspace for one search of nq queries at depth k: the maximum over every chunk size the pass loop will use — the
 // full chunk AND the remainder (a smaller chunk can need MORE slab-list space: slabs(m) * m is not monotone in m).
@@ -680,39 +690,63 @@ int two_level_pass(amdr_dense* h, int ws, const float* Qc, int m, int k, int kc_
   TwoLevelPlan t;
   two_level_plan(h, m, k, kc, &t);
   float* M = h->smat[ws].as<float>();
-  float* S2 = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(h->smat[ws].p) + t.m_bytes);
+  unsigned char* s2p = reinterpret_cast<unsigned char*>(h->smat[ws].p) + t.m_bytes;
+  float* S2 = reinterpret_cast<float*>(s2p);
   unsigned char* aux = reinterpret_cast<unsigned char*>(h->aux[ws].p);
   int64_t* tile_ids = reinterpret_cast<int64_t*>(aux);
   float* tile_max = reinterpret_cast<float*>(aux + (size_t)m * kc * sizeof(int64_t));
   int* list = reinterpret_cast<int*>(aux + (size_t)m * kc * (sizeof(int64_t) + sizeof(float)));
   int* count = list + (size_t)m * kc;
   int rc;
-  float* hi_mt = nullptr;
-  // 1. tile maxima (the scan: this is the launch the profiling events bracket)
   const bool prof = !gate && h->prof_on && (size_t)(h->prof_used + 2) <= h->prof_ev.size();
-  if (prof) AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
   if (hi) {
-    float* MT = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(S2) +
-                                         ((size_t)m * t.pass2.ld * sizeof(float) + 255) / 256 * 256);
-    rc = dense_hi_launch_tilemax(h->X, (long)h->n, h->d, Qc, m, MT, st, h->x_scale);
-    hi_mt = MT;
+    // 1a. maxima of a strided sample of the tiles -> per query the kc-th best = the threshold of the full scan
+    float* MT = reinterpret_cast<float*>(s2p + t.s2_own);
+    void* cand = s2p + t.s2_own + t.mt_bytes;
+    int64_t* ts_ids = reinterpret_cast<int64_t*>(count + 64);
+    float* ts_max = reinterpret_cast<float*>(ts_ids + (size_t)m * kc);
+    unsigned int* total = reinterpret_cast<unsigned int*>(flag) + 16;
+    if ((rc = dense_hi_launch_sample(h->X, (long)h->n, h->d, Qc, m, MT, st, h->x_scale))) return rc;
+    if ((rc = dense_hi_launch_transpose(MT, t.sample_items, m, t.tk1.ld, M, st))) return rc;
+    if ((rc = topk_pass(t.tk1, M, t.sample_items, m, kc, h->part[ws], ts_max, ts_ids, st))) return rc;
+    AMDR_HIP(hipMemsetAsync(total, 0, sizeof(unsigned int), st));
+    // 1b. the scan (the launch the profiling events bracket): maxima that reach the threshold -> flat candidate list
+    if (prof) AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
+    if ((rc = dense_hi_launch_emit(h->X, (long)h->n, h->d, Qc, m, ts_max + (kc - 1), kc, cand, total, t.cand_entries, st,
+                                   h->x_scale)))
+      return rc;
+    if (prof) {
+      AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
+      h->prof_used += 2;
+    }
+    // 2. kc candidate tiles per query; is the cut wide enough?
+    int nparts = 0;
+    if ((rc = dense_hi_launch_cand_topk(cand, total, t.cand_entries, m, kc, h->part[ws].p, &nparts, st))) return rc;
+    {
+      const int mcap = topk_cap(kc);
+      const size_t lds = (size_t)kWaves * mcap * sizeof(C32) + kWaves * sizeof(int);
+      hipLaunchKernelGGL(dense_merge_kernel, dim3(m), dim3(256), lds, st, h->part[ws].as<C32>(), nparts, m, kc, mcap, tile_max,
+                         (long long*)tile_ids, (const int*)nullptr);
+      AMDR_HIP(hipGetLastError());
+    }
+    h->hi_queries += m;
+    if ((rc = dense_hi_launch_check(tile_max, tile_ids, m, kc, k, Qc, h->d, h->row_norm_max, h->x_scale, t.tiles, total,
+                                    t.cand_entries, flag, h->stats.as<unsigned int>() + 2, st)))
+      return rc;
   } else {
+    // 1. tile maxima (the scan: this is the launch the profiling events bracket)
+    if (prof) AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
     DenseMfmaPlan scan = t.scan;
     scan.ld = t.tk1.ld;
-    rc = dense_mfma_launch_scores(scan, h->X, (long)h->n, h->d, Qc, m, M, st, 1, nullptr, nullptr, 0, gate);
+    if ((rc = dense_mfma_launch_scores(scan, h->X, (long)h->n, h->d, Qc, m, M, st, 1, nullptr, nullptr, 0, gate))) return rc;
+    if (prof) {
+      AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
+      h->prof_used += 2;
+    }
+    // 2. k candidate tiles per query
+    if ((rc = topk_pass(t.tk1, M, t.tiles, m, kc, h->part[ws], tile_max, tile_ids, st, gate))) return rc;
   }
-  if (rc) return rc;
-  if (prof) {
-    AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
-    h->prof_used += 2;
-  }
-  if (hi && (rc = dense_hi_launch_transpose(hi_mt, (long)h->n, m, t.tk1.ld, M, st))) return rc;
-  // 2. kc candidate tiles per query, their sorted union
-  if ((rc = topk_pass(t.tk1, M, t.tiles, m, kc, h->part[ws], tile_max, tile_ids, st, gate))) return rc;
-  if (hi) h->hi_queries += m;
-  if (hi && (rc = dense_hi_launch_check(tile_max, m, kc, k, Qc, h->d, h->row_norm_max, h->x_scale, t.tiles, flag,
-                                          h->stats.as<unsigned int>() + 2, st)))
-    return rc;
+  // ... their sorted union
   if ((rc = dense_tiles_unique_launch(tile_ids, m * kc, t.tiles, list, count, st, gate))) return rc;
   // 3. exact scores of the candidate tiles' rows
   if ((rc = dense_mfma_launch_scores(t.pass2, h->X, t.cand_rows, h->d, Qc, m, S2, st, 2, list, count, (long)h->n, gate)))
@@ -1110,9 +1144,9 @@ int amdr_dense_plan_info(const amdr_dense_t* h, int32_t nq, int32_t k, char* buf
     two_level_plan(h, m, k, kc, &t);
     snprintf(buf, buf_len,
              "dense_hi_tilemax_kernel fp16 first pass queries_per_launch=%d two-level: top-%d of %ld approximate tile "
-             "maxima (width level %d), cut checked against the rounding bound + exact re-scoring of <= %d candidate tiles "
-             "+ top-k (exact first pass behind a device flag)",
-             m, kc, t.tiles, hi_level_of(h), m * kc);
+             "maxima (width level %d; threshold from a sample of every %ld-th tile), cut checked against the rounding bound "
+             "+ exact re-scoring of <= %d candidate tiles + top-k (exact first pass behind a device flag)",
+             m, kc, t.tiles, hi_level_of(h), dense_hi_sample_stride((long)h->n), m * kc);
     return AMDR_OK;
   }
   if (hi_applies(h, nq, k)) {  // the handle gave the fp16 pass up: exact passes in the same shapes

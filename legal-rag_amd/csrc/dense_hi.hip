@@ -42,11 +42,27 @@ __device__ __forceinline__ int hi_q_off(int q, int chunk, int d) { return q * (d
 // grid: 1-D over row slabs; LDS: 64 x d halves (query tile) + kHiWaves x 4 KiB (stages).  M[q][tile] is the maximum of
 // (x * x_scale) . (q * 2^-e_q) over the tile's rows — a per-query positive scaling of the scores, which is all a
 // per-query ranking of tiles needs; keeping the scaled value keeps it clear of fp32's subnormal range
-template <int D64>  // d / 64
+// EMIT = false: item i of the launch is tile i * tile_stride (a strided SAMPLE of the tiles), its maxima go to MT[i][cols].
+// EMIT = true (the full scan, tile_stride 1): a tile's maximum leaves the kernel only if it reaches tau[query] — the kc-th
+// best maximum of the sample, a lower bound of the kc-th best overall, so every tile of a query's global top-kc passes
+// — as a packed (score, query << 26 | tile) entry of ONE flat list: staged in a wave-private LDS buffer, appended with one
+// atomic per flush (normally one per wave and launch).  ~kc x tile_stride entries per query instead of every maximum.
+struct HiEmit {
+  const float* tau;     // [nq], stride tau_stride floats
+  int tau_stride;
+  C32* cand;            // flat list
+  unsigned int* total;  // entries appended (may pass cap: the check kernel raises the flag)
+  unsigned int cap;
+  int wbuf;             // entries of the wave-private staging buffer
+};
+constexpr int kHiQShift = 26;  // tiles < 2^26
+
+template <int D64, bool EMIT>  // d / 64
 __global__ __launch_bounds__(kHiWaves * 64) void dense_hi_tilemax_kernel(const float* __restrict__ X, long n,
                                                                          const float* __restrict__ Q, int nq,
-                                                                         float* __restrict__ MT /*[tiles][cols]*/,
-                                                                         int cols, float x_scale) {
+                                                                         float* __restrict__ MT /*[items][cols]*/,
+                                                                         int cols, float x_scale, long tile_stride,
+                                                                         long n_items, HiEmit em) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int d = D64 * 64;
   constexpr int NCH = D64;
@@ -83,13 +99,12 @@ __global__ __launch_bounds__(kHiWaves * 64) void dense_hi_tilemax_kernel(const f
   // Persistent block (one per CU: the query tile is converted once).  Every wave of the grid owns one contiguous run
   // of tiles (run lengths differ by at most one tile) and streams it front to back; its loads run two 64-float chunks
   // ahead, across tile boundaries.
-  const long tiles = (n + 31) >> 5;
   const long gw = (long)blockIdx.x * kHiWaves + wave, nw = (long)gridDim.x * kHiWaves;
-  const long t_lo = tiles * gw / nw, t_hi = tiles * (gw + 1) / nw;
+  const long t_lo = n_items * gw / nw, t_hi = n_items * (gw + 1) / nw;  // this wave's run of items
   // loader role inside a 1-KiB piece: 4 rows x 256 B; lane: row l >> 4, 16-B piece l & 15 (4 floats)
   const int lrow = lane >> 4, lpiece = lane & 15;
-  auto row_ptr = [&](long tile, int p) {
-    long r = tile * 32 + 4 * p + lrow;
+  auto row_ptr = [&](long item, int p) {
+    long r = item * tile_stride * 32 + 4 * p + lrow;
     if (r >= n) r = n - 1;  // rows past the end repeat the last row: no effect on a maximum
     return X + (size_t)r * d + lpiece * 4;
   };
@@ -110,6 +125,19 @@ __global__ __launch_bounds__(kHiWaves * 64) void dense_hi_tilemax_kernel(const f
   float mt[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) mt[j] = 0.f;
+  // EMIT: the wave's staging buffer and its fill (wave-uniform), the lane's threshold
+  C32* wbuf = reinterpret_cast<C32*>(smem + 64 * d * 2 + kHiWaves * kHiStageBytes) + (size_t)wave * (EMIT ? em.wbuf : 0);
+  int wcnt = 0;
+  const float tau = (EMIT && lane < nq) ? em.tau[(size_t)lane * em.tau_stride] : 0.f;
+  auto flush = [&]() {
+    unsigned int base = 0;
+    if (lane == 0) base = atomicAdd(em.total, (unsigned int)wcnt);
+    base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+    for (int i = lane; i < wcnt; i += 64)
+      if (base + (unsigned int)i < em.cap) em.cand[base + i] = wbuf[i];
+    wcnt = 0;
+    wave_lds_fence();
+  };
   for (long t = t_lo; t < t_hi; ++t) {
     const bool has_next = t + 1 < t_hi;
     const float* gp[8];
@@ -171,24 +199,75 @@ __global__ __launch_bounds__(kHiWaves * 64) void dense_hi_tilemax_kernel(const f
       for (int j = 1; j < 16; ++j) m = fmaxf(m, acc[b][j]);
       mq[b] = fmaxf(m, __uint_as_float(lane_xor<32>(__float_as_uint(m))));
     }
-    // In the scaled units of the lane's query (see the check kernel).  MT[tile][cols], cols = the queries rounded up to
-    // 16: one contiguous row per tile, the rows of a wave's run back to back.  Two measured facts shape this (timing-only build without any store:
-    // 4.38 ms per scan): written [query][tile], every tile's 64 maxima went to 64 different DRAM pages — 20 M scattered
-    // partial writes that cost 0.9 ms; and a store in the wave's instruction stream holds back the vmcnt of every load
-    // issued after it until it is acknowledged (~3 us a time) — one store per tile cost 0.47 ms even with contiguous rows.
-    // Hence: the maxima of 8 tiles wait in registers and leave as 8 back-to-back row stores, 19 times per wave.
+    // In the scaled units of the lane's query (see the check kernel).
     const float mine = h ? mq[1] : mq[0];
-    const int j8 = (int)((t - t_lo) & 7);
+    if (EMIT) {
+      // What the maxima cost when all of them were written (timing-only build without any store: 4.38 ms per scan):
+      // M[query][tile], a 4-byte store per (tile, query): 5.1-5.3 ms — 64 DRAM pages per instruction; MT[tile][queries]
+      // rows + a transposition: 4.84 ms + 70 us + a 95-us top-k over 20 M values.  Here: only maxima that reach the
+      // sample's threshold, through LDS.
+      const bool pass = lane < nq && mine >= tau;
+      const unsigned long long pm = __ballot(pass);
+      if (pm != 0ull) {  // wave-uniform
+        const unsigned long long below = lane == 0 ? 0ull : (pm & (~0ull >> (64 - lane)));
+        if (pass) wbuf[wcnt + __popcll(below)] = C32::make(mine, ((unsigned int)lane << kHiQShift) | (unsigned int)t);
+        wcnt += __popcll(pm);
+        if (wcnt + 64 > em.wbuf) flush();
+      }
+    } else {
+      // MT[item][cols], cols = the queries rounded up to 16: one contiguous row per item, the maxima of 8 items collected
+      // in registers and written as 8 back-to-back row stores.
+      const int j8 = (int)((t - t_lo) & 7);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) mt[j] = j8 == j ? mine : mt[j];
-    if (j8 == 7 || !has_next) {  // wave-uniform
-      float* dst = MT + (size_t)(t - j8) * cols + lane;
-      if (lane < cols) {
+      for (int j = 0; j < 8; ++j) mt[j] = j8 == j ? mine : mt[j];
+      if (j8 == 7 || !has_next) {  // wave-uniform
+        float* dst = MT + (size_t)(t - j8) * cols + lane;
+        if (lane < cols) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (j <= j8) dst[(size_t)j * cols] = mt[j];
+          for (int j = 0; j < 8; ++j)
+            if (j <= j8) dst[(size_t)j * cols] = mt[j];
+        }
       }
     }
+  }
+  if (EMIT && wcnt > 0) flush();
+}
+
+// Top-kc of every query from the flat list of the emitting scan, step 1: block (part p, query q) reads the p-th slice of
+// the list (from L2), keeps the query's entries, writes its best kc as part[p][q][kc] — the layout dense_merge_kernel
+// merges.  (score desc, tile asc) like every other top-k here.  One block per query over the whole list took 227 us.
+constexpr int kHiCandParts = 16;
+__global__ __launch_bounds__(256) void dense_hi_cand_topk_kernel(const C32* __restrict__ cand,
+                                                                 const unsigned int* __restrict__ total, unsigned int cap,
+                                                                 int nq, int kc, int tcap, C32* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  C32* lists = reinterpret_cast<C32*>(smem);
+  int* cnts = reinterpret_cast<int*>(lists + (size_t)4 * tcap);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned int qi = blockIdx.y;
+  WaveTopK<C32> tk;
+  tk.init(lists + (size_t)wave * tcap, tcap, kc);
+  unsigned int n = *total;
+  if (n > cap) n = cap;
+  const unsigned int per = (n + gridDim.x - 1) / gridDim.x;
+  const unsigned int lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  for (unsigned int base = lo + (unsigned int)wave * 64; base < hi; base += 256) {
+    const unsigned int i = base + lane;
+    bool v = i < hi;
+    C32 c = C32::pad();
+    if (v) {
+      c = cand[i];
+      const unsigned int id = 0xffffffffu - (unsigned int)c.c;
+      v = (id >> kHiQShift) == qi;
+      c.c = (c.c & 0xffffffff00000000ull) | (u64)(0xffffffffu - (id & ((1u << kHiQShift) - 1u)));
+    }
+    tk.push_lanes(c, v, lane);
+  }
+  tk.finalize(lane);
+  block_combine_topk(tk, lists, tcap, 4, wave, lane, cnts);
+  if (wave == 0) {
+    C32* out = part + ((size_t)blockIdx.x * nq + qi) * kc;
+    for (int j = lane; j < kc; j += 64) out[j] = j < tk.cnt ? tk.buf[j] : C32::pad();
   }
 }
 
@@ -196,21 +275,17 @@ __global__ __launch_bounds__(kHiWaves * 64) void dense_hi_tilemax_kernel(const f
 constexpr int kHiTrTiles = 256;
 __host__ __device__ inline int hi_mt_cols(int nq) { return (nq + 15) & ~15; }
 __global__ __launch_bounds__(256) void dense_hi_transpose_kernel(const float* __restrict__ MT, long tiles, int nq, long ldM,
-                                                                 float* __restrict__ M) {
+                                                                 float* __restrict__ M, int tpb /* <= kHiTrTiles, x 64 */) {
   __shared__ float patch[kHiTrTiles][65];
-  const long t0 = (long)blockIdx.x * kHiTrTiles;
+  const long t0 = (long)blockIdx.x * tpb;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cols = hi_mt_cols(nq);
-  for (int r = wave; r < kHiTrTiles; r += 4)
+  for (int r = wave; r < tpb; r += 4)
     if (t0 + r < tiles && lane < cols) patch[r][lane] = MT[(size_t)(t0 + r) * cols + lane];
   __syncthreads();
-  for (int q = wave; q < nq; q += 4) {
-#pragma unroll
-    for (int j = 0; j < kHiTrTiles / 64; ++j) {
-      const int r = lane + 64 * j;
+  for (int q = wave; q < nq; q += 4)
+    for (int r = lane; r < tpb; r += 64)
       if (t0 + r < tiles) M[(size_t)q * ldM + t0 + r] = patch[r][q];
-    }
-  }
 }
 
 // largest |component| and largest row L2 norm of a matrix (float bits; both are non-negative)
@@ -254,6 +329,8 @@ __global__ __launch_bounds__(256) void dense_stats_kernel(const float* __restric
 __global__ __launch_bounds__(64) void dense_hi_check_kernel(const float* __restrict__ vals, int kc1, int k,
                                                             const float* __restrict__ Q, int d, float row_norm_max,
                                                             float x_scale, int x_exp, long n_tiles,
+                                                            const long long* __restrict__ ids,
+                                                            const unsigned int* __restrict__ total, unsigned int cap,
                                                             int* __restrict__ flag, unsigned int* __restrict__ unresolved) {
   const int q = blockIdx.x, lane = threadIdx.x;
   float amax = 0.f;
@@ -282,7 +359,10 @@ __global__ __launch_bounds__(64) void dense_hi_check_kernel(const float* __restr
   const bool bad = nan || !(amax <= FLT_MAX) || !(eps == eps) || e + x_exp > 100 || e + x_exp < -100;
   const float* v = vals + (size_t)q * kc1;
   bool raise = bad;
-  if (!bad && n_tiles >= kc1) {  // fewer tiles than candidates: every tile is one already
+  // the flat candidate list overflowed (the sample's threshold let too many maxima pass), or the query has fewer than kc1
+  // candidates (a NaN threshold: fewer than kc1 sample tiles with a real maximum): the exact chain decides
+  if (*total > cap || ids[(size_t)q * kc1 + kc1 - 1] < 0) raise = true;
+  if (!raise && n_tiles >= kc1) {  // fewer tiles than candidates: every tile is one already
     const float Tk = v[k - 1], last = v[kc1 - 1];
     raise = !(last < Tk - 2.f * eps);
   }
@@ -295,59 +375,109 @@ __global__ __launch_bounds__(64) void dense_hi_check_kernel(const float* __restr
 // (d = 1 024: the 128-KiB query tile + the stages would take all 160 KiB of LDS and the kernel all 256 VGPRs: not built)
 bool dense_hi_supported(int d) { return d >= 128 && d <= 896 && d % 128 == 0; }
 
-size_t dense_hi_lds(int d) { return (size_t)64 * d * 2 + kHiWaves * kHiStageBytes; }
+static int hi_wbuf_entries(int d) { return d <= 768 ? 256 : 128; }  // 16 / 8 KiB of LDS for the 8 waves
+static size_t dense_hi_lds(int d, bool emit) {
+  return (size_t)64 * d * 2 + kHiWaves * kHiStageBytes + (emit ? (size_t)kHiWaves * hi_wbuf_entries(d) * sizeof(C32) : 0);
+}
 
-template <int D64>
-static int launch_hi(const float* X, long n, const float* Q, int nq, int grid, float* MT, float x_scale, hipStream_t st) {
-  AMDR_HIP(hipFuncSetAttribute((const void*)dense_hi_tilemax_kernel<D64>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)dense_hi_lds(D64 * 64)));
-  hipLaunchKernelGGL((dense_hi_tilemax_kernel<D64>), dim3(grid), dim3(kHiWaves * 64), dense_hi_lds(D64 * 64), st, X, n, Q, nq,
-                     MT, hi_mt_cols(nq), x_scale);
+template <int D64, bool EMIT>
+static int launch_hi(const float* X, long n, const float* Q, int nq, int grid, float* MT, float x_scale, long tile_stride,
+                     long n_items, const HiEmit& em, hipStream_t st) {
+  const size_t lds = dense_hi_lds(D64 * 64, EMIT);
+  AMDR_HIP(hipFuncSetAttribute((const void*)dense_hi_tilemax_kernel<D64, EMIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+  hipLaunchKernelGGL((dense_hi_tilemax_kernel<D64, EMIT>), dim3(grid), dim3(kHiWaves * 64), lds, st, X, n, Q, nq, MT,
+                     hi_mt_cols(nq), x_scale, tile_stride, n_items, em);
   AMDR_HIP(hipGetLastError());
   return AMDR_OK;
 }
 
-size_t dense_hi_mt_bytes(long n) { return (size_t)((n + 31) / 32) * 64 * sizeof(float); }
-
-// approximate tile maxima of <= 64 queries: the scan writes MT[tile][64] (dense_hi_mt_bytes), the transposition M[q][tile]
-int dense_hi_launch_tilemax(const float* X, long n, int d, const float* Q, int nq, float* MT, hipStream_t st, float x_scale) {
+template <bool EMIT>
+static int launch_hi_d(const float* X, long n, int d, const float* Q, int nq, float* MT, float x_scale, long tile_stride,
+                       const HiEmit& em, hipStream_t st) {
   if (!dense_hi_supported(d) || nq < 1 || nq > 64) return fail(AMDR_EINVAL, "dense (fp16 first pass): d=%d nq=%d", d, nq);
   // one persistent block per CU (the query tile fills most of its LDS)
   int dev = 0, cus = 256;
   AMDR_HIP(hipGetDevice(&dev));
   AMDR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   const long tiles = (n + 31) / 32;
-  long blocks = (tiles + kHiWaves - 1) / kHiWaves;
+  const long n_items = (tiles + tile_stride - 1) / tile_stride;
+  long blocks = (n_items + kHiWaves - 1) / kHiWaves;
   if (blocks > cus) blocks = cus;
   if (blocks < 1) blocks = 1;
   const int grid = (int)blocks;
   switch (d / 64) {
-    case 2: return launch_hi<2>(X, n, Q, nq, grid, MT, x_scale, st);
-    case 4: return launch_hi<4>(X, n, Q, nq, grid, MT, x_scale, st);
-    case 6: return launch_hi<6>(X, n, Q, nq, grid, MT, x_scale, st);
-    case 8: return launch_hi<8>(X, n, Q, nq, grid, MT, x_scale, st);
-    case 10: return launch_hi<10>(X, n, Q, nq, grid, MT, x_scale, st);
-    case 12: return launch_hi<12>(X, n, Q, nq, grid, MT, x_scale, st);
-    case 14: return launch_hi<14>(X, n, Q, nq, grid, MT, x_scale, st);
+    case 2: return launch_hi<2, EMIT>(X, n, Q, nq, grid, MT, x_scale, tile_stride, n_items, em, st);
+    case 4: return launch_hi<4, EMIT>(X, n, Q, nq, grid, MT, x_scale, tile_stride, n_items, em, st);
+    case 6: return launch_hi<6, EMIT>(X, n, Q, nq, grid, MT, x_scale, tile_stride, n_items, em, st);
+    case 8: return launch_hi<8, EMIT>(X, n, Q, nq, grid, MT, x_scale, tile_stride, n_items, em, st);
+    case 10: return launch_hi<10, EMIT>(X, n, Q, nq, grid, MT, x_scale, tile_stride, n_items, em, st);
+    case 12: return launch_hi<12, EMIT>(X, n, Q, nq, grid, MT, x_scale, tile_stride, n_items, em, st);
+    case 14: return launch_hi<14, EMIT>(X, n, Q, nq, grid, MT, x_scale, tile_stride, n_items, em, st);
     default: return fail(AMDR_EINVAL, "dense (fp16 first pass): unsupported dim %d", d);
   }
 }
 
-int dense_hi_launch_transpose(const float* MT, long n, int nq, long ldM, float* M, hipStream_t st) {
+// the sample: every tile_stride-th tile; ~2 048-4 096 of them (a power-of-two stride <= 256), every tile of a short matrix
+long dense_hi_sample_stride(long n) {
   const long tiles = (n + 31) / 32;
-  hipLaunchKernelGGL(dense_hi_transpose_kernel, dim3((unsigned)((tiles + kHiTrTiles - 1) / kHiTrTiles)), dim3(256), 0, st, MT,
-                     tiles, nq, ldM, M);
+  long s = 1;
+  while (s < 256 && tiles / (2 * s) >= 2048) s *= 2;
+  return s;
+}
+long dense_hi_sample_items(long n) {
+  const long tiles = (n + 31) / 32, s = dense_hi_sample_stride(n);
+  return (tiles + s - 1) / s;
+}
+size_t dense_hi_mt_bytes(long n) { return (size_t)dense_hi_sample_items(n) * 64 * sizeof(float); }
+// entries of the flat candidate list: 4x the expected m * kc * stride, at least 64 Ki
+size_t dense_hi_cand_entries(long n, int m, int kc) {
+  size_t e = (size_t)m * kc * dense_hi_sample_stride(n) * 4 + 65536;
+  const size_t all = (size_t)((n + 31) / 32) * m;  // never more than every maximum
+  return e < all ? e : all + 64;
+}
+
+// maxima of the sampled tiles of <= 64 queries: MT[item][cols]
+int dense_hi_launch_sample(const float* X, long n, int d, const float* Q, int nq, float* MT, hipStream_t st, float x_scale) {
+  HiEmit em{};
+  return launch_hi_d<false>(X, n, d, Q, nq, MT, x_scale, dense_hi_sample_stride(n), em, st);
+}
+// the full scan: every tile maximum >= tau[q * tau_stride] into the flat list (*total zeroed by the caller)
+int dense_hi_launch_emit(const float* X, long n, int d, const float* Q, int nq, const float* tau, int tau_stride, void* cand,
+                         unsigned int* total, size_t cap, hipStream_t st, float x_scale) {
+  if ((n + 31) / 32 >= (1l << kHiQShift)) return fail(AMDR_EINVAL, "dense (fp16 first pass): too many tiles");
+  HiEmit em{tau, tau_stride, (C32*)cand, total, (unsigned int)cap, hi_wbuf_entries(d)};
+  return launch_hi_d<true>(X, n, d, Q, nq, nullptr, x_scale, 1, em, st);
+}
+size_t dense_hi_cand_part_bytes(int m, int kc) { return (size_t)kHiCandParts * m * kc * sizeof(C32); }
+// step 1 of the candidates' top-kc: part[kHiCandParts][m][kc] (dense_hi_cand_part_bytes); the caller merges the parts
+int dense_hi_launch_cand_topk(const void* cand, const unsigned int* total, size_t cap, int m, int kc, void* part,
+                              int* nparts, hipStream_t st) {
+  const int tcap = topk_cap(kc);
+  const size_t lds = (size_t)4 * tcap * sizeof(C32) + 4 * sizeof(int);
+  hipLaunchKernelGGL(dense_hi_cand_topk_kernel, dim3(kHiCandParts, m), dim3(256), lds, st, (const C32*)cand, total,
+                     (unsigned int)cap, m, kc, tcap, (C32*)part);
+  AMDR_HIP(hipGetLastError());
+  *nparts = kHiCandParts;
+  return AMDR_OK;
+}
+
+int dense_hi_launch_transpose(const float* MT, long items, int nq, long ldM, float* M, hipStream_t st) {
+  const int tpb = items >= 64 * 1024 ? kHiTrTiles : 64;  // a short sample: more, smaller blocks
+  hipLaunchKernelGGL(dense_hi_transpose_kernel, dim3((unsigned)((items + tpb - 1) / tpb)), dim3(256), 0, st, MT, items, nq, ldM,
+                     M, tpb);
   AMDR_HIP(hipGetLastError());
   return AMDR_OK;
 }
 
-int dense_hi_launch_check(const float* vals, int m, int kc1, int k, const float* Q, int d, float row_norm_max, float x_scale,
-                          long n_tiles, int* flag, unsigned int* unresolved, hipStream_t st) {
+int dense_hi_launch_check(const float* vals, const int64_t* ids, int m, int kc1, int k, const float* Q, int d,
+                          float row_norm_max, float x_scale, long n_tiles, const unsigned int* total, size_t cap, int* flag,
+                          unsigned int* unresolved, hipStream_t st) {
   int x_exp = 0;
   (void)frexpf(x_scale, &x_exp);  // x_scale = 2^-ex = 0.5 * 2^(1 - ex)
   x_exp = 1 - x_exp;
   hipLaunchKernelGGL(dense_hi_check_kernel, dim3(m), dim3(64), 0, st, vals, kc1, k, Q, d, row_norm_max, x_scale, x_exp, n_tiles,
-                     flag, unresolved);
+                     (const long long*)ids, total, (unsigned int)cap, flag, unresolved);
   AMDR_HIP(hipGetLastError());
   return AMDR_OK;
 }
@@ -355,7 +485,9 @@ int dense_hi_launch_check(const float* vals, int m, int kc1, int k, const float*
 // max |component| and max row norm of X[row0 .. row0 + n): out2 must hold two zeroed unsigned ints
 int dense_stats_launch(const float* X, long n, int d, unsigned int* out2, hipStream_t st) {
   if (n <= 0) return AMDR_OK;
-  hipLaunchKernelGGL(dense_stats_kernel, dim3(2048), dim3(256), 0, st, X, n, d, out2);
+  long blocks = (n + 3) / 4;  // a wave per row and round
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(dense_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, st, X, n, d, out2);
   AMDR_HIP(hipGetLastError());
   return AMDR_OK;
 }
