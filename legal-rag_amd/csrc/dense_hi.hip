@@ -375,7 +375,11 @@ __global__ __launch_bounds__(64) void dense_hi_check_kernel(const float* __restr
 // (d = 1 024: the 128-KiB query tile + the stages would take all 160 KiB of LDS and the kernel all 256 VGPRs: not built)
 bool dense_hi_supported(int d) { return d >= 128 && d <= 896 && d % 128 == 0; }
 
-static int hi_wbuf_entries(int d) { return d <= 768 ? 256 : 128; }  // 16 / 8 KiB of LDS for the 8 waves
+static int hi_wbuf_entries(int d) {  // 16 / 8 KiB of LDS for the 8 waves
+  const char* e = getenv("AMDR_DENSE_HI_WBUF");  // test hook: a 64-entry buffer flushes after every emitting tile
+  if (e && atoi(e) >= 64 && atoi(e) <= 128) return atoi(e);
+  return d <= 768 ? 256 : 128;
+}
 static size_t dense_hi_lds(int d, bool emit) {
   return (size_t)64 * d * 2 + kHiWaves * kHiStageBytes + (emit ? (size_t)kHiWaves * hi_wbuf_entries(d) * sizeof(C32) : 0);
 }
@@ -433,6 +437,8 @@ size_t dense_hi_mt_bytes(long n) { return (size_t)dense_hi_sample_items(n) * 64 
 // entries of the flat candidate list: 4x the expected m * kc * stride, at least 64 Ki
 size_t dense_hi_cand_entries(long n, int m, int kc) {
   size_t e = (size_t)m * kc * dense_hi_sample_stride(n) * 4 + 65536;
+  const char* env = getenv("AMDR_DENSE_HI_CAP");  // test hook: a short list overflows -> the exact chain takes over
+  if (env && atol(env) >= 64) e = (size_t)atol(env);
   const size_t all = (size_t)((n + 31) / 32) * m;  // never more than every maximum
   return e < all ? e : all + 64;
 }

@@ -277,3 +277,35 @@ def test_hi_first_pass_is_given_up_on_a_matrix_it_cannot_resolve(nat, monkeypatc
     assert np.array_equal(gi, ex[1]) and np.array_equal(gs.view(np.uint32), ex[0].view(np.uint32))
     for b in range(0, len(Q), 97):
         assert (gi[b] % 1600 == gi[b, 0] % 1600).all() and gi[b].tolist() == sorted(gi[b].tolist())
+
+
+def test_hi_first_pass_candidate_list_flushes_and_overflow(nat, monkeypatch):
+    """The emitting scan stages its candidates in a wave-private LDS buffer and appends them to one flat list.  A 64-entry
+    buffer (test hook) flushes after every emitting tile: the entries must arrive intact — same results, nothing
+    unresolved.  A list too short for the candidates (test hook; in production: a threshold that lets too much pass)
+    raises the flag: every query through the exact chain, same results."""
+    rng = np.random.default_rng(41)
+    X, Q = unit_rows(rng, 20011, 256), unit_rows(rng, 64, 256)
+    ref = three_forms(nat, monkeypatch, X, Q, 10)
+    assert_same(ref, "reference")
+    monkeypatch.setenv("AMDR_DENSE_HI_WBUF", "64")
+    out = three_forms(nat, monkeypatch, X, Q, 10)
+    assert_same(out, "64-entry staging buffer")
+    assert out["counters"][:2] == (64, 0) and np.array_equal(out["hi"][1], ref["hi"][1])
+    monkeypatch.delenv("AMDR_DENSE_HI_WBUF")
+    monkeypatch.setenv("AMDR_DENSE_HI_CAP", "500")  # 64 queries x 33 candidates do not fit
+    out = three_forms(nat, monkeypatch, X, Q, 10)
+    assert_same(out, "overflowing candidate list")
+    assert out["counters"][:2] == (64, 64)
+    monkeypatch.delenv("AMDR_DENSE_HI_CAP")
+    # a constant matrix: every tile maximum ties -> every tile of every query is emitted (several flushes per wave, the
+    # list's real capacity exceeded) -> exact chain -> the ten lowest ids
+    Xc = np.tile(unit_rows(rng, 1, 128), (300_000, 1))
+    monkeypatch.setenv("AMDR_DENSE_TWO_LEVEL", "1")
+    monkeypatch.setenv("AMDR_DENSE_HI", "1")
+    idx = nat.DenseIndex(Xc)
+    s, i = idx.search(unit_rows(rng, 64, 128), 10)
+    took, bad = idx.hi_counters()[:2]
+    idx.close()
+    assert (took, bad) == (64, 64)
+    assert (i == np.arange(10)[None, :]).all() and (s == s[:, :1]).all()
