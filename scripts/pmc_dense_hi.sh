@@ -12,8 +12,8 @@ run() { # name, counters...
   echo "pass $n rc=$?" >> $O/progress.log
 }
 [ -z "$SKIP_EA" ] && run ea_$B TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_sum
-run sq1_$B SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
-run sq2_$B SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
+[ -z "$SKIP_SQ" ] && run sq1_$B SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
+[ -z "$SKIP_SQ" ] && run sq2_$B SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 cd $R
 for d in ea_$B sq1_$B sq2_$B; do f=$(find $O/$d -name "*counter_collection.csv" 2>/dev/null | head -1); echo "== $d"; [ -n "$f" ] && python3 scripts/summarize_rocprof.py --pmc $f | grep -i "hi_tilemax\|transpose\|kernel |\|---" ; done
 cat $O/progress.log
