@@ -87,14 +87,16 @@ void dense_mfma_plan(long n, int d, int nq, int k, DenseMfmaPlan* p);
 // (dense_hi.hip) is enqueued unconditionally and decides on the device whether it runs
 int dense_mfma_launch_scores(const DenseMfmaPlan& p, const float* X, long n, int d, const float* Q, int nq, float* S,
                              hipStream_t st, int mode = 0, const int* tile_list = nullptr,
-                             const int* tile_count = nullptr, long n_real = 0, const int* gate = nullptr);
+                             const int* tile_count = nullptr, long n_real = 0, const int* gate = nullptr,
+                             int list_stride = 0);
 // two-level top-k helpers: sorted unique list of the candidate tiles (a bitmap in LDS up to kUniqueBitmapTilesMax tiles,
 // any number of candidates; beyond, a one-wave sort of <= 8 192 candidates); column -> row id of the final hits
 constexpr int kUniqueBitmapTilesMax = 1 << 20;
 int dense_tiles_unique_launch(const int64_t* tile_ids, int n_in, long n_tiles, int* list, int* count, hipStream_t st,
                               const int* gate = nullptr);
+int dense_tiles_sort_per_query_launch(const int64_t* tile_ids, int m, int kc, int* list, int* count, hipStream_t st);
 int dense_tiles_remap_launch(int64_t* ids, int total, const int* list, const int* count, long n_real, hipStream_t st,
-                             const int* gate = nullptr);
+                             const int* gate = nullptr, int k = 1, int list_stride = 0);
 int dense_mfma_launch_topk(const DenseMfmaPlan& p, const float* S, long n, int nq, int k, void* part,
                            float* fin_scores, int64_t* fin_ids, hipStream_t st, const int* gate = nullptr);
 

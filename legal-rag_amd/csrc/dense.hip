@@ -587,8 +587,17 @@ void two_level_plan(const amdr_dense* h, int m, int k, int kc, TwoLevelPlan* t) 
   t->sample_items = hi ? dense_hi_sample_items((long)h->n) : 0;
   dense_mfma_plan((long)h->n, h->d, m, k, &t->scan);
   dense_mfma_plan(hi ? t->sample_items : t->tiles, h->d, m, kc, &t->tk1);  // only its top-k half is used: columns = tiles
-  t->cand_rows = (long)m * kc * 32;
+  // exact form: every query of the pass against the UNION of their candidate tiles (one list); behind the fp16 pass a
+  // query against its own kc tiles (mode 3 of the scores kernel: block row = query, <= 16 tiles per block)
+  t->cand_rows = hi ? (long)kc * 32 : (long)m * kc * 32;
   dense_mfma_plan(t->cand_rows, h->d, m, k, &t->pass2);
+  if (hi) {
+    // a (query, tile) pass is 11.7 us of fp32 matrix time on one SIMD: as few tiles per SIMD as one round of blocks allows
+    const int gx = (kc + 15) / 16;
+    t->pass2.rows_per_block = (long)((kc + gx - 1) / gx) * 32;
+    t->pass2.grid_x = (int)((t->cand_rows + t->pass2.rows_per_block - 1) / t->pass2.rows_per_block);
+    t->pass2.grid_y = m;
+  }
   t->m_bytes = ((size_t)m * t->tk1.ld * sizeof(float) + 255) / 256 * 256;
   t->s2_own = ((size_t)m * t->pass2.ld * sizeof(float) + 255) / 256 * 256;
   t->mt_bytes = hi ? (dense_hi_mt_bytes((long)h->n) + 255) / 256 * 256 : 0;
@@ -745,6 +754,14 @@ int two_level_pass(amdr_dense* h, int ws, const float* Qc, int m, int k, int kc_
     }
     // 2. k candidate tiles per query
     if ((rc = topk_pass(t.tk1, M, t.tiles, m, kc, h->part[ws], tile_max, tile_ids, st, gate))) return rc;
+  }
+  if (hi) {
+    // 3. every query's own candidate tiles, ascending; their exact scores; 4. top-k, columns -> row ids
+    if ((rc = dense_tiles_sort_per_query_launch(tile_ids, m, kc, list, count, st))) return rc;
+    if ((rc = dense_mfma_launch_scores(t.pass2, h->X, t.cand_rows, h->d, Qc, m, S2, st, 3, list, count, (long)h->n, nullptr, kc)))
+      return rc;
+    if ((rc = topk_pass(t.pass2, S2, t.cand_rows, m, k, h->part[ws], out_scores, out_ids, st))) return rc;
+    return dense_tiles_remap_launch(out_ids, m * k, list, count, (long)h->n, st, nullptr, k, kc);
   }
   // ... their sorted union
   if ((rc = dense_tiles_unique_launch(tile_ids, m * kc, t.tiles, list, count, st, gate))) return rc;

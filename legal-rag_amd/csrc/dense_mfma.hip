@@ -115,7 +115,7 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
                                                                  float* __restrict__ S /*[queries][ldS]*/, int mode,
                                                                  const int* __restrict__ tile_list,
                                                                  const int* __restrict__ tile_count, long n_real,
-                                                                 const int* __restrict__ gate) {
+                                                                 const int* __restrict__ gate, int list_stride) {
   if (gate != nullptr && *gate == 0) return;  // a gated launch (dense_hi.hip): decided on the device, block-uniform
   // mode 0: S[query][row] for every row.
   // mode 1: S[query][tile] = MAXIMUM of the query's scores over the 32-row tile (first pass of the two-level
@@ -123,6 +123,9 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
   // mode 2: `n` counts VIRTUAL rows, 32 per entry of tile_list; virtual tile t reads chunk tile tile_list[t]
   //         (t < *tile_count, else it is filled with -FLT_MAX) and writes S[query][32 t ..]: the exact re-scoring of
   //         the candidate tiles — same loads, same MFMA k order, the same bits as mode 0.
+  // mode 3: mode 2 PER QUERY: block row `by` is query `by` alone (the LDS tile holds it in row 0, zeros below), its
+  //         candidate tiles are tile_list[by * list_stride ..], tile_count[by] of them, its scores S[by][32 t ..]:
+  //         a query is scored against its own candidates only, not against the union of a whole batch's.
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int d = D8 * 8;
   constexpr int NCH = d / kKC;  // chunks per row: 12 / 24 / 32 (always even: d % 64 == 0)
@@ -159,7 +162,13 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
     bx = logical / gy;
     by = logical - bx * gy;
   }
-  const int q0 = by * 32;
+  int q0 = by * 32;
+  if (mode == 3) {
+    q0 = by;
+    nq = by + 1;
+    tile_list += (size_t)by * list_stride;
+    tile_count += by;
+  }
 
   // ---- stage the query tile, row-major with a per-row XOR swizzle of the 16-byte slots:
   //   qs[i * d/4 + (k4 ^ (i & 15))] = Q[q0+i][4*k4 .. 4*k4+3]
@@ -202,10 +211,10 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
   // loader role of this lane inside a 1-KiB piece: 8 rows x 8 slots
   const int lrow = lane >> 3, lslot = lane & 7;
 
-  const int n_list = (mode == 2) ? *tile_count : 0;
+  const int n_list = (mode >= 2) ? *tile_count : 0;
   for (long r0 = row_lo + (long)wave * 32; r0 < row_hi; r0 += (long)WAVES * 32) {
     long src0 = r0, src_hi = row_hi;  // rows actually read
-    if (mode == 2) {
+    if (mode >= 2) {
       const int t = (int)(r0 >> 5);
       if (t >= n_list) {  // beyond the candidate list: columns that can never win
 #pragma unroll
@@ -310,7 +319,7 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
 #pragma unroll
         for (int bj = 0; bj < 2; ++bj) {
           f32x4 v = acc[bi][bj];
-          if (mode == 2) {  // rows past the end of the matrix inside the last tile are no candidates
+          if (mode >= 2) {  // rows past the end of the matrix inside the last tile are no candidates
 #pragma unroll
             for (int r = 0; r < 4; ++r)
               if (src0 + 16 * bj + 4 * kq + r >= n_real) v[r] = -FLT_MAX;
@@ -465,6 +474,11 @@ __global__ __launch_bounds__(64) void tiles_unique_kernel(const long long* __res
   if (gate != nullptr && *gate == 0) return;
   C32* buf = reinterpret_cast<C32*>(smem);
   const int lane = threadIdx.x;
+  // block b sorts ids [b * n_in, (b + 1) * n_in) into list + b * n_in, count[b]: one block for the union of a batch,
+  // one per query for the per-query candidate lists behind the fp16 first pass
+  tile_ids += (size_t)blockIdx.x * n_in;
+  list += (size_t)blockIdx.x * n_in;
+  count += blockIdx.x;
   for (int i = lane; i < cap; i += 64) {
     const long long v = i < n_in ? tile_ids[i] : -1ll;
     buf[i].c = v >= 0 ? (u64)(v + 1) : 0ull;
@@ -549,10 +563,14 @@ __global__ __launch_bounds__(1024) void tiles_unique_bitmap_kernel(const long lo
 __global__ __launch_bounds__(256) void tiles_remap_ids_kernel(long long* __restrict__ ids, int total,
                                                               const int* __restrict__ list,
                                                               const int* __restrict__ count, long n_real,
-                                                              const int* __restrict__ gate) {
+                                                              const int* __restrict__ gate, int k, int list_stride) {
   if (gate != nullptr && *gate == 0) return;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < total) {
+    if (list_stride > 0) {  // per-query lists: entry i belongs to query i / k
+      list += (size_t)(i / k) * list_stride;
+      count += i / k;
+    }
     const long long c = ids[i];
     if (c >= 0) {
       // a filler column (beyond the candidate list, or past the end of the matrix inside the last tile: score
@@ -583,10 +601,19 @@ int dense_tiles_unique_launch(const int64_t* tile_ids, int n_in, long n_tiles, i
   AMDR_HIP(hipGetLastError());
   return AMDR_OK;
 }
+// one sorted duplicate-free list per query: ids [m][kc] -> list [m][kc] (ascending), count [m]
+int dense_tiles_sort_per_query_launch(const int64_t* tile_ids, int m, int kc, int* list, int* count, hipStream_t st) {
+  int cap = 64;
+  while (cap < kc) cap <<= 1;
+  hipLaunchKernelGGL(tiles_unique_kernel, dim3(m), dim3(64), (size_t)cap * sizeof(C32), st, (const long long*)tile_ids, kc, cap,
+                     list, count, (const int*)nullptr);
+  AMDR_HIP(hipGetLastError());
+  return AMDR_OK;
+}
 int dense_tiles_remap_launch(int64_t* ids, int total, const int* list, const int* count, long n_real, hipStream_t st,
-                             const int* gate) {
+                             const int* gate, int k, int list_stride) {
   hipLaunchKernelGGL(tiles_remap_ids_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, (long long*)ids, total, list,
-                     count, n_real, gate);
+                     count, n_real, gate, k, list_stride);
   AMDR_HIP(hipGetLastError());
   return AMDR_OK;
 }
@@ -653,7 +680,7 @@ void dense_mfma_plan(long n, int d, int nq, int k, DenseMfmaPlan* p) {
 template <int D8, int WAVES, bool NTL>
 static int launch_scores(const DenseMfmaPlan& p, const float* X, long n, const float* Q, int nq, float* S,
                          hipStream_t st, int mode, const int* tile_list, const int* tile_count, long n_real,
-                         const int* gate) {
+                         const int* gate, int list_stride) {
   // 128-160 KiB of dynamic LDS needs the opt-in.  The attribute belongs to the (function, device)
   // pair, the C ABI takes a device ordinal, and setting it is cheap: set on every launch for the
   // current device rather than remembering "done" per process.
@@ -662,20 +689,20 @@ static int launch_scores(const DenseMfmaPlan& p, const float* X, long n, const f
                                D8 * 8 * 32 * (int)sizeof(float) + WAVES * kStageBufs * kStageBytes));
   hipLaunchKernelGGL((dense_mfma_scores_kernel<D8, WAVES, NTL>), dim3(p.grid_x * p.grid_y), dim3(WAVES * 64),
                      p.lds_scores, st, X, n, Q, nq, p.rows_per_block, p.grid_x, p.grid_y, p.ld, S, mode, tile_list, tile_count,
-                     n_real, gate);
+                     n_real, gate, list_stride);
   return AMDR_OK;
 }
 
 int dense_mfma_launch_scores(const DenseMfmaPlan& p, const float* X, long n, int d, const float* Q, int nq, float* S,
                              hipStream_t st, int mode, const int* tile_list, const int* tile_count, long n_real,
-                             const int* gate) {
+                             const int* gate, int list_stride) {
   int rc = AMDR_OK;
-  const bool nt = dense_stream_nontemporal(mode == 2 ? n_real : n, d) && mode != 2;  // candidate tiles are re-read: cacheable
+  const bool nt = dense_stream_nontemporal(mode >= 2 ? n_real : n, d) && mode < 2;  // candidate tiles are re-read: cacheable
   switch (d) {
 #define AMDR_CASE(D)                                                          \
   case D:                                                                     \
-    rc = nt ? launch_scores<D / 8, scores_waves(D), true>(p, X, n, Q, nq, S, st, mode, tile_list, tile_count, n_real, gate)   \
-            : launch_scores<D / 8, scores_waves(D), false>(p, X, n, Q, nq, S, st, mode, tile_list, tile_count, n_real, gate); \
+    rc = nt ? launch_scores<D / 8, scores_waves(D), true>(p, X, n, Q, nq, S, st, mode, tile_list, tile_count, n_real, gate, list_stride)   \
+            : launch_scores<D / 8, scores_waves(D), false>(p, X, n, Q, nq, S, st, mode, tile_list, tile_count, n_real, gate, list_stride); \
     break;
     AMDR_CASE(64) AMDR_CASE(128) AMDR_CASE(192) AMDR_CASE(256) AMDR_CASE(320) AMDR_CASE(384)
     AMDR_CASE(448) AMDR_CASE(512) AMDR_CASE(576) AMDR_CASE(640) AMDR_CASE(704) AMDR_CASE(768)
