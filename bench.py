@@ -732,7 +732,7 @@ def run_scale_synth10m(torch, dist, world, rank, local, device, n_total, B, step
 
     for _ in range(warmup):
         step()
-    idx.profile_begin(steps * 3)
+    idx.profile_begin(steps * 3 * max(1, (B + 63) // 64))  # every scan launch of the three windows
     dts = timed_windows(torch, dist, world, device, step, steps, 0, 3)
     scan_ms, launches = idx.profile_end()
     st = window_stats(dts, steps)
@@ -972,7 +972,7 @@ def main():
             for name, fn in (("full_hybrid_rerank_sharded",
                               lambda: run_full_hybrid_rerank(torch, local, K, max(3, min(a.steps, 10)), dist, world, rank)),
                              ("scale_synth10m",
-                              lambda: run_scale_synth10m(torch, dist, world, rank, local, device, a.synth_rows, 64, 10, 3))):
+                              lambda: run_scale_synth10m(torch, dist, world, rank, local, device, a.synth_rows, 256, 10, 3))):
                 try:
                     sc = fn()
                 except Exception as e:  # noqa: BLE001
