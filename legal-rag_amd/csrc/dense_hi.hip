@@ -6,16 +6,21 @@
 // peak and cannot hold more than 32 queries (a 96-KiB fp32 query tile in LDS).  The first pass only has to find
 // candidate tiles, and the second pass is exact — so here it runs on v_mfma_f32_32x32x16_f16 with fp16 ROUNDINGS of
 // both operands (hi parts, csrc/maxsim.hip): 16x the matrix rate, a 96-KiB tile now holds 64 queries, the scan is
-// bound by HBM alone.  |x^ . q^ - x . q| <= (2^-10 + 2^-22 + 768 * 2^-24) |x| |q| is a proven bound, the candidate
-// cut is widened by it (dense.hip run_search_hi_two_level), the re-scoring pass is the unchanged exact fp32 kernel:
-// ids and score bits are those of the exact forms.  A query whose cut the bound does not separate (mass near-ties)
-// raises a device flag and the exact first pass runs for that batch (gated launches: no host round trip).
+// bound by HBM alone.  Every approximate tile maximum lies within a proven eps of the exact one (dense_hi_check_kernel
+// states the bound), the candidate cut is widened by it (dense.hip run_search_two_level / two_level_pass), the
+// re-scoring pass is the unchanged exact fp32 kernel: ids and score bits are those of the exact forms.  A query whose
+// cut the bound does not separate (mass near-ties) raises a device flag and the exact first pass runs for that batch
+// (gated launches: no host round trip).
 //
-// Kernel: a block = 8 waves; the query tile — up to 64 queries converted to fp16 (per-query power-of-two scale) —
-// sits in LDS for the whole block; every wave streams 32-row tiles of X: coalesced 16-B/lane fp32 loads (4 rows x
-// 256 B per wave instruction, non-temporal, 2 chunks of 64 floats per row in flight), conversion to fp16 in
-// registers (the matrix's power-of-two scale applied), a wave-private 4-KiB fp16 stage in LDS, fragments back, 8
-// MFMAs per 64-float chunk (32 rows x 64 queries).  Per tile and query only the MAXIMUM leaves the kernel.
+// Kernel: a persistent block of 8 waves per CU; the query tile — up to 64 queries converted to fp16 (per-query
+// power-of-two scale) — sits in LDS for the whole launch; every wave streams its own contiguous run of 32-row tiles of X:
+// coalesced 16-B/lane fp32 loads (4 rows x 256 B per wave instruction, non-temporal, 2 chunks of 64 floats per row in
+// flight across tile boundaries), conversion to fp16 in registers (the matrix's power-of-two scale applied), a
+// wave-private 4-KiB fp16 stage in LDS, fragments back, 8 MFMAs per 64-float chunk (32 rows x 64 queries), one maximum per
+// tile and query.  Two launches per search: a SAMPLE of every s-th tile writes its maxima (MT[item][queries]) and gives
+// each query a threshold (the kc-th best sampled maximum, a lower bound of the kc-th best overall); the full SCAN then
+// lets only the maxima that reach the threshold leave the kernel, as entries of one flat candidate list.  Writing all
+// 20 M maxima of a 10 M-row scan cost 0.3-0.9 ms of 5 whatever the layout.
 #include "common.hpp"
 #include "topk.hpp"
 
