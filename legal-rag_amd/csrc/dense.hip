@@ -585,7 +585,7 @@ void two_level_plan(const amdr_dense* h, int m, int k, int kc, TwoLevelPlan* t) 
   const bool hi = kc != k;
   t->tiles = ((long)h->n + 31) / 32;
   t->sample_items = hi ? dense_hi_sample_items((long)h->n) : 0;
-  dense_mfma_plan((long)h->n, h->d, m, k, &t->scan);
+  if (!hi) dense_mfma_plan((long)h->n, h->d, m, k, &t->scan);  // the exact first pass only
   dense_mfma_plan(hi ? t->sample_items : t->tiles, h->d, m, kc, &t->tk1);  // only its top-k half is used: columns = tiles
   // exact form: every query of the pass against the UNION of their candidate tiles (one list); behind the fp16 pass a
   // query against its own kc tiles (mode 3 of the scores kernel: block row = query, <= 16 tiles per block)
