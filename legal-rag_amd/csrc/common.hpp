@@ -102,6 +102,7 @@ int dense_mfma_launch_topk(const DenseMfmaPlan& p, const float* S, long n, int n
 
 // ---- fp16 first pass of the two-level top-k on large matrices: dense_hi.hip ----
 bool dense_hi_supported(int d);
+int dense_hi_max_queries(int d);  // queries per scan: 64, 48 at d = 1 024
 long dense_hi_sample_stride(long n);
 long dense_hi_sample_items(long n);
 size_t dense_hi_mt_bytes(long n);                       // maxima of the sample, [items][64]

@@ -544,7 +544,7 @@ bool hi_applies(const amdr_dense* h, int nq, int k) {
   return dense_stream_nontemporal((long)h->n, h->d) && tiles >= 64L * hi_kc_max(k);
 }
 int hi_chunk(const amdr_dense* h, int nq, int k) {  // the same at every level: a handle's passes keep their shape when its level moves
-  int c = 64;
+  int c = dense_hi_max_queries(h->d);
   // the candidate union is a bitmap over the tiles (any number of candidates) up to 2^20 tiles; beyond, the one-wave sort
   // and its 8 192-candidate limit (>= 32 queries for every admitted k)
   if (((long)h->n + 31) / 32 > kUniqueBitmapTilesMax && kTwoLevelTilesMax / hi_kc_max(k) < c) c = kTwoLevelTilesMax / hi_kc_max(k);

@@ -43,6 +43,7 @@ constexpr int kHiStageBytes = 32 * 128;  // 32 rows x 64 halves
 __device__ __forceinline__ int hi_stage_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
 // query tile: row q (0..63) at byte q * (d * 2), its 16-B chunk c at c ^ (q & 15) (rows alias on the banks: d * 2 % 256 == 0)
 __device__ __forceinline__ int hi_q_off(int q, int chunk, int d) { return q * (d * 2) + ((chunk ^ (q & 15)) << 4); }
+__host__ __device__ constexpr int hi_query_tile(int d) { return d > 896 ? 48 : 64; }
 
 // grid: 1-D over row slabs; LDS: 64 x d halves (query tile) + kHiWaves x 4 KiB (stages).  M[q][tile] is the maximum of
 // (x * x_scale) . (q * 2^-e_q) over the tile's rows — a per-query positive scaling of the scores, which is all a
@@ -71,13 +72,14 @@ __global__ __launch_bounds__(kHiWaves * 64) void dense_hi_tilemax_kernel(const f
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int d = D64 * 64;
   constexpr int NCH = D64;
+  constexpr int QT = hi_query_tile(d);  // queries of the LDS tile: 64, or 48 at d = 1 024 (96 KiB either way at the widest)
   unsigned char* qt = smem;
-  unsigned char* stage = smem + 64 * d * 2 + (threadIdx.x >> 6) * kHiStageBytes;
+  unsigned char* stage = smem + QT * d * 2 + (threadIdx.x >> 6) * kHiStageBytes;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r32 = lane & 31, h = lane >> 5;
 
   // ---- the query tile: wave w converts queries 8 w .. 8 w + 7 (scale = 2^-e of the query's largest |component|)
-  for (int qi = wave * 8; qi < wave * 8 + 8; ++qi) {
+  for (int qi = wave * 8; qi < wave * 8 + 8 && qi < QT; ++qi) {
     const bool live = qi < nq;
     const float* src = Q + (size_t)(live ? qi : 0) * d;
     float v[D64];
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(kHiWaves * 64) void dense_hi_tilemax_kernel(const f
 #pragma unroll
   for (int j = 0; j < 8; ++j) mt[j] = 0.f;
   // EMIT: the wave's staging buffer and its fill (wave-uniform), the lane's threshold
-  C32* wbuf = reinterpret_cast<C32*>(smem + 64 * d * 2 + kHiWaves * kHiStageBytes) + (size_t)wave * (EMIT ? em.wbuf : 0);
+  C32* wbuf = reinterpret_cast<C32*>(smem + QT * d * 2 + kHiWaves * kHiStageBytes) + (size_t)wave * (EMIT ? em.wbuf : 0);
   int wcnt = 0;
   const float tau = (EMIT && lane < nq) ? em.tau[(size_t)lane * em.tau_stride] : 0.f;
   auto flush = [&]() {
@@ -189,7 +191,9 @@ __global__ __launch_bounds__(kHiWaves * 64) void dense_hi_tilemax_kernel(const f
         const h8 a = *reinterpret_cast<const h8*>(stage + hi_stage_off(r32, 2 * s + h));
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-          const h8 q = *reinterpret_cast<const h8*>(qt + hi_q_off(32 * b + r32, 8 * c + 2 * s + h, d));
+          // (a 48-query tile has no rows 48..63: the second block's upper columns re-read rows 32..47 and are never used)
+          const int qrow = b == 0 ? r32 : 32 + (QT == 64 ? r32 : (r32 & 15));
+          const h8 q = *reinterpret_cast<const h8*>(qt + hi_q_off(qrow, 8 * c + 2 * s + h, d));
           acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, q, acc[b], 0, 0, 0);
         }
       }
@@ -384,8 +388,9 @@ __global__ __launch_bounds__(64) void dense_hi_check_kernel(const float* __restr
   }
 }
 
-// (d = 1 024: the 128-KiB query tile + the stages would take all 160 KiB of LDS and the kernel all 256 VGPRs: not built)
-bool dense_hi_supported(int d) { return d >= 128 && d <= 896 && d % 128 == 0; }
+// d = 1 024: a 48-query tile (96 KiB; 64 queries + the stages would take all 160 KiB of LDS)
+bool dense_hi_supported(int d) { return d >= 128 && d <= 1024 && d % 128 == 0; }
+int dense_hi_max_queries(int d) { return hi_query_tile(d); }
 
 static int hi_wbuf_entries(int d) {  // 16 / 8 KiB of LDS for the 8 waves
   const char* e = getenv("AMDR_DENSE_HI_WBUF");  // test hook: a 64-entry buffer flushes after every emitting tile
@@ -393,7 +398,7 @@ static int hi_wbuf_entries(int d) {  // 16 / 8 KiB of LDS for the 8 waves
   return d <= 768 ? 256 : 128;
 }
 static size_t dense_hi_lds(int d, bool emit) {
-  return (size_t)64 * d * 2 + kHiWaves * kHiStageBytes + (emit ? (size_t)kHiWaves * hi_wbuf_entries(d) * sizeof(C32) : 0);
+  return (size_t)hi_query_tile(d) * d * 2 + kHiWaves * kHiStageBytes + (emit ? (size_t)kHiWaves * hi_wbuf_entries(d) * sizeof(C32) : 0);
 }
 
 template <int D64, bool EMIT>
@@ -411,7 +416,7 @@ static int launch_hi(const float* X, long n, const float* Q, int nq, int grid, f
 template <bool EMIT>
 static int launch_hi_d(const float* X, long n, int d, const float* Q, int nq, float* MT, float x_scale, long tile_stride,
                        const HiEmit& em, hipStream_t st) {
-  if (!dense_hi_supported(d) || nq < 1 || nq > 64) return fail(AMDR_EINVAL, "dense (fp16 first pass): d=%d nq=%d", d, nq);
+  if (!dense_hi_supported(d) || nq < 1 || nq > hi_query_tile(d)) return fail(AMDR_EINVAL, "dense (fp16 first pass): d=%d nq=%d", d, nq);
   // one persistent block per CU (the query tile fills most of its LDS)
   int dev = 0, cus = 256;
   AMDR_HIP(hipGetDevice(&dev));
@@ -430,6 +435,7 @@ static int launch_hi_d(const float* X, long n, int d, const float* Q, int nq, fl
     case 10: return launch_hi<10, EMIT>(X, n, Q, nq, grid, MT, x_scale, tile_stride, n_items, em, st);
     case 12: return launch_hi<12, EMIT>(X, n, Q, nq, grid, MT, x_scale, tile_stride, n_items, em, st);
     case 14: return launch_hi<14, EMIT>(X, n, Q, nq, grid, MT, x_scale, tile_stride, n_items, em, st);
+    case 16: return launch_hi<16, EMIT>(X, n, Q, nq, grid, MT, x_scale, tile_stride, n_items, em, st);
     default: return fail(AMDR_EINVAL, "dense (fp16 first pass): unsupported dim %d", d);
   }
 }

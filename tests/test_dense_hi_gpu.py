@@ -58,7 +58,7 @@ def assert_same(out, what):
 def test_hi_first_pass_same_ids_and_bits(nat, monkeypatch):
     rng = np.random.default_rng(2024)
     cases = [(9017, 128, 64, 10), (9000, 256, 5, 1), (7777, 384, 33, 10), (9017, 768, 70, 10), (8200, 896, 130, 3),
-             (12017, 512, 64, 80), (30011, 128, 129, 40), (7100, 640, 17, 10)]
+             (12017, 512, 64, 80), (30011, 128, 129, 40), (7100, 640, 17, 10), (9017, 1024, 48, 10), (8200, 1024, 130, 5)]
     unresolved = 0
     for n, d, nq, k in cases:
         X, Q = unit_rows(rng, n, d), unit_rows(rng, nq, d)
@@ -75,7 +75,7 @@ def test_hi_first_pass_unsupported_shapes_take_the_exact_form(nat, monkeypatch):
     rng = np.random.default_rng(5)
     monkeypatch.setenv("AMDR_DENSE_HI", "1")
     monkeypatch.setenv("AMDR_DENSE_TWO_LEVEL", "1")
-    for n, d, nq, k in ((9000, 1024, 33, 10), (9000, 192, 33, 10), (9000, 768, 4, 10), (9000, 768, 33, 128),
+    for n, d, nq, k in ((9000, 192, 33, 10), (9000, 64, 33, 10), (9000, 768, 4, 10), (9000, 768, 33, 128),
                         (1200, 768, 33, 10)):
         idx = nat.DenseIndex(unit_rows(rng, n, d))
         assert "dense_hi" not in idx.plan_info(nq, k), (n, d, nq, k)
