@@ -673,7 +673,7 @@ def _hbm_scan_one(torch, _native, device, X, Q, n, d, B, steps, warmup, k):
     if hi:
         # the fp16 first pass only picks candidate tiles: ids and score bits must be those of the exact first pass, on
         # the FULL matrix; and how many queries its rounding bound could not resolve (their batches also ran the exact pass)
-        took, unresolved, level, in_use = idx.hi_counters()
+        took, unresolved, level, in_use, passes, flagged = idx.hi_counters()
         hs, hids = s.cpu().numpy().copy(), i.cpu().numpy().copy()
         os.environ["AMDR_DENSE_HI"] = "0"
         try:
@@ -688,7 +688,8 @@ def _hbm_scan_one(torch, _native, device, X, Q, n, d, B, steps, warmup, k):
             del os.environ["AMDR_DENSE_HI"]
         extra = {"fp16_first_pass": {"queries": took, "unresolved_by_the_rounding_bound": unresolved,
                                      "full_matrix_ids_and_score_bits_equal_exact_first_pass": same,
-                                     "queries_per_scan": per_scan, "width_level": level, "in_use": in_use}}
+                                     "queries_per_scan": per_scan, "width_level": level, "in_use": in_use,
+                                     "passes": passes, "passes_that_also_ran_the_exact_chain": flagged}}
     per_launch_ms = scan_ms / max(launches, 1)
     achieved = bytes_per_launch / (per_launch_ms * 1e-3) / 1e9
     out = {"workload": f"synthetic {n}x{d} fp32 rows in HBM, {B} queries/scan, top-{k}", "kernel": kernel, "plan": plan,

@@ -96,13 +96,14 @@ int amdr_dense_workspace_plan(int64_t n, int32_t d, int32_t nq, int32_t k, int64
  * proven rounding bound and the second pass is the exact fp32 kernel, so ids and score bits are those of the exact
  * forms (csrc/dense_hi.hip).  A query whose cut the bound does not separate sends its batch through the exact first
  * pass as well (decided on the device).  The width of the candidate cut adapts per handle: k + max(k, 22 / 54 / 96)
- * + 1 tiles per query (levels 0-2); a handle that sees more than 10 % of >= 256 queries unresolved moves up a level,
- * at the top level more than 25 % make it give the fp16 pass up (exact passes from then on); AMDR_DENSE_HI_LEVEL pins
- * the level.  out4[0] = queries that took the fp16 first pass since creation, out4[1] = those it could not resolve,
- * out4[2] = current level, out4[3] = 1 while the pass is in use.  Synchronises the device.  The matrix wrapped by
- * amdr_dense_create_from_device must not change while the handle lives (its largest component and row norm are
- * measured at creation). */
-int amdr_dense_hi_counters(amdr_dense_t* h, int64_t* out4);
+ * + 1 tiles per query (levels 0-2).  One unresolved query sends its whole pass (<= 64 queries) through the exact chain,
+ * so passes are what is counted: more than 10 % of >= 4 passes flagged moves the handle up a level, at the top level
+ * more than half make it give the fp16 pass up (exact passes from then on); AMDR_DENSE_HI_LEVEL pins the level.
+ * out6[0] = queries that took the fp16 first pass since creation, out6[1] = those it could not resolve, out6[2] =
+ * current level, out6[3] = 1 while the pass is in use, out6[4] = passes, out6[5] = passes whose flag went up.
+ * Synchronises the device.  The matrix wrapped by amdr_dense_create_from_device must not change while the handle
+ * lives (its largest component and row norm are measured at creation). */
+int amdr_dense_hi_counters(amdr_dense_t* h, int64_t* out6);
 /* HIP-event bracket around the scan kernel alone (not the merge), recorded on
  * the stream each search is launched on; used by bench.py for the roofline.
  * begin() arms up to max_launches event pairs, end() returns the summed scan

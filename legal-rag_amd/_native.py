@@ -250,12 +250,12 @@ class DenseIndex:
                "amdr_dense_plan_info")
         return buf.value.decode()
 
-    def hi_counters(self) -> Tuple[int, int, int, bool]:
-        """(queries that took the fp16 first pass of large scans, those it could not resolve — their batches also
-        ran the exact first pass —, current width level 0-2, pass still in use).  Synchronises the device."""
-        out = (C.c_int64 * 4)()
+    def hi_counters(self) -> Tuple[int, int, int, bool, int, int]:
+        """(queries that took the fp16 first pass of large scans, those it could not resolve, current width level 0-2,
+        pass still in use, passes, passes that also ran the exact chain).  Synchronises the device."""
+        out = (C.c_int64 * 6)()
         _check(load().amdr_dense_hi_counters(self._h, out), "amdr_dense_hi_counters")
-        return int(out[0]), int(out[1]), int(out[2]), bool(out[3])
+        return int(out[0]), int(out[1]), int(out[2]), bool(out[3]), int(out[4]), int(out[5])
 
     def profile_begin(self, max_launches: int) -> None:
         _check(load().amdr_dense_profile_begin(self._h, C.c_int32(max_launches)), "amdr_dense_profile_begin")

@@ -319,9 +319,10 @@ struct amdr_dense {
   // queries the rounding bound keeps failing to resolve moves up a level, and at the top level gives the pass up
   int hi_level = 0;
   bool hi_off = false;
-  int64_t lvl_q0 = 0;           // hi_queries / unresolved counter when the current level was entered
-  unsigned int lvl_u0 = 0;
-  unsigned int* hi_host = nullptr;  // pinned: the device's unresolved-query counter, copied back after every pass
+  int64_t hi_passes = 0;        // passes (<= 64 queries each) through the fp16 first pass
+  int64_t lvl_p0 = 0;           // hi_passes / flagged-pass counter when the current level was entered
+  unsigned int lvl_f0 = 0;
+  unsigned int* hi_host = nullptr;  // pinned: the device's (unresolved queries, flagged passes), copied back after every search
   // optional HIP-event ring bracketing the scan kernel alone (bench.py roofline)
   std::vector<hipEvent_t> prof_ev;
   int prof_used = 0;
@@ -550,25 +551,28 @@ int hi_chunk(const amdr_dense* h, int nq, int k) {  // the same at every level: 
   if (((long)h->n + 31) / 32 > kUniqueBitmapTilesMax && kTwoLevelTilesMax / hi_kc_max(k) < c) c = kTwoLevelTilesMax / hi_kc_max(k);
   return nq < c ? nq : c;
 }
-// Between searches (host side, no synchronisation: the counter is whatever the last completed copy-back left).
+// Between searches (host side, no synchronisation: the counters are whatever the last completed copy-back left).  One
+// unresolved query sends its whole pass through the exact chain as well (+2 scans for a 1-scan pass), so what is
+// counted is PASSES whose flag went up: more than 10 % of >= 4 passes at this width -> the next width (+3 % per pass);
+// at the widest, more than half -> the exact passes alone are cheaper (1 + 2 f > 2).
 void hi_adapt(amdr_dense* h) {
   if (!h->hi_host || h->hi_off || getenv("AMDR_DENSE_HI_LEVEL")) return;
-  const unsigned int u = *(volatile unsigned int*)h->hi_host;
-  const int64_t q = h->hi_queries - h->lvl_q0;
-  const int64_t bad = (int64_t)(u - h->lvl_u0);
-  if (q < 256) return;
+  const unsigned int f = ((volatile unsigned int*)h->hi_host)[1];
+  const int64_t p = h->hi_passes - h->lvl_p0;
+  const int64_t bad = (int64_t)(f - h->lvl_f0);
+  if (p < 4) return;
   bool move = false;
   if (h->hi_level + 1 < kHiLevels) {
-    move = bad * 10 > q;  // > 10 % of the level's queries went through the exact chain as well
+    move = bad * 10 > p;
     if (move) ++h->hi_level;
   } else {
     const char* e = getenv("AMDR_DENSE_HI");
-    move = bad * 4 > q && !(e && e[0] == '1');  // top level, > 25 %: this matrix is not for the fp16 pass
+    move = bad * 2 > p && !(e && e[0] == '1');  // this matrix is not for the fp16 pass
     if (move) h->hi_off = true;
   }
-  if (move || q >= (1 << 20)) {  // a new window
-    h->lvl_q0 = h->hi_queries;
-    h->lvl_u0 = u;
+  if (move || p >= (1 << 16)) {  // a new window
+    h->lvl_p0 = h->hi_passes;
+    h->lvl_f0 = f;
   }
 }
 
@@ -739,6 +743,7 @@ int two_level_pass(amdr_dense* h, int ws, const float* Qc, int m, int k, int kc_
       AMDR_HIP(hipGetLastError());
     }
     h->hi_queries += m;
+    h->hi_passes += 1;
     if ((rc = dense_hi_launch_check(tile_max, tile_ids, m, kc, k, Qc, h->d, h->row_norm_max, h->x_scale, t.tiles, total,
                                     t.cand_entries, flag, h->stats.as<unsigned int>() + 2, st)))
       return rc;
@@ -807,7 +812,7 @@ int run_search_two_level(amdr_dense* h, int ws, const float* Q_dev, int nq, int 
     }
   }
   if (kc_hi && h->hi_host)  // what hi_adapt reads before the next search
-    AMDR_HIP(hipMemcpyAsync(h->hi_host, h->stats.as<unsigned int>() + 2, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+    AMDR_HIP(hipMemcpyAsync(h->hi_host, h->stats.as<unsigned int>() + 2, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
   return AMDR_OK;
 }
 
@@ -869,7 +874,7 @@ int update_stats(amdr_dense* h, int64_t row0, int64_t rows) {
   if (row0 == 0) AMDR_HIP(hipMemsetAsync(h->stats.p, 0, 4 * sizeof(unsigned int), h->stream));
   if (!h->hi_host) {
     AMDR_HIP(hipHostMalloc((void**)&h->hi_host, 4 * sizeof(unsigned int), hipHostMallocDefault));
-    h->hi_host[0] = 0u;
+    h->hi_host[0] = h->hi_host[1] = 0u;
   }
   if ((rc = dense_stats_launch(h->X + (size_t)row0 * h->d, (long)rows, h->d, h->stats.as<unsigned int>(), h->stream)))
     return rc;
@@ -1212,21 +1217,22 @@ int amdr_dense_plan_info(const amdr_dense_t* h, int32_t nq, int32_t k, char* buf
   return AMDR_OK;
 }
 
-int amdr_dense_hi_counters(amdr_dense_t* h, int64_t* out4) {
-  int64_t* out2 = out4;
-  AMDR_REQUIRE(h && out4, "dense_hi_counters: null");
+int amdr_dense_hi_counters(amdr_dense_t* h, int64_t* out6) {
+  AMDR_REQUIRE(h && out6, "dense_hi_counters: null");
   std::lock_guard<std::mutex> g(h->mu);
   AMDR_HIP(hipSetDevice(h->device));
-  out2[0] = h->hi_queries;
-  out2[1] = 0;
+  out6[0] = h->hi_queries;
+  out6[1] = out6[5] = 0;
   if (h->stats.p) {
-    unsigned int c = 0;
-    AMDR_HIP(hipDeviceSynchronize());  // the counter is bumped by kernels on the callers' streams
-    AMDR_HIP(hipMemcpy(&c, h->stats.as<unsigned int>() + 2, sizeof(c), hipMemcpyDeviceToHost));
-    out2[1] = (int64_t)c;
+    unsigned int c[2] = {0, 0};
+    AMDR_HIP(hipDeviceSynchronize());  // the counters are bumped by kernels on the callers' streams
+    AMDR_HIP(hipMemcpy(c, h->stats.as<unsigned int>() + 2, sizeof(c), hipMemcpyDeviceToHost));
+    out6[1] = (int64_t)c[0];
+    out6[5] = (int64_t)c[1];
   }
-  out4[2] = hi_level_of(h);
-  out4[3] = h->hi_ok && !h->hi_off ? 1 : 0;
+  out6[2] = hi_level_of(h);
+  out6[3] = h->hi_ok && !h->hi_off ? 1 : 0;
+  out6[4] = h->hi_passes;
   return AMDR_OK;
 }
 

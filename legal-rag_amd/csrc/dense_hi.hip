@@ -383,8 +383,8 @@ __global__ __launch_bounds__(64) void dense_hi_check_kernel(const float* __restr
     raise = !(last < Tk - 2.f * eps);
   }
   if (raise) {
-    atomicOr(flag, 1);
-    atomicAdd(unresolved, 1u);  // amdr_dense_hi_counters
+    if (atomicOr(flag, 1) == 0) atomicAdd(unresolved + 1, 1u);  // passes whose flag went up (the first query to raise it)
+    atomicAdd(unresolved, 1u);                                   // queries; both: amdr_dense_hi_counters
   }
 }
 
