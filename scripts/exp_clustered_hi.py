@@ -1,0 +1,65 @@
+"""How the fp16 first pass of large scans behaves on CLUSTERED rows (what real embedding matrices look like: many near
+neighbours around a query's best rows): rows = normalize(centre + spread * noise) over C centres, queries near centres.
+Prints, per spread, the adaptive width level reached, the share of unresolved queries / flagged passes, ms per 64-query
+search against the exact first pass, and whether ids and score bits agree."""
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from legal_rag_amd import _native  # noqa: E402
+
+dev = torch.device("cuda:0")
+n, d, C = int(os.environ.get("N", 4_000_000)), 768, int(os.environ.get("C", 20_000))
+g = torch.Generator(device=dev).manual_seed(7)
+centres = torch.nn.functional.normalize(torch.randn(C, d, device=dev, generator=g), dim=1)
+
+
+def build(spread):
+    X = torch.empty(n, d, device=dev)
+    for lo in range(0, n, 500_000):
+        hi = min(n, lo + 500_000)
+        c = torch.randint(0, C, (hi - lo,), device=dev, generator=g)
+        X[lo:hi] = torch.nn.functional.normalize(centres[c] + spread * torch.randn(hi - lo, d, device=dev, generator=g) / d ** 0.5, dim=1)
+    return X
+
+
+def run(X, Q, hi, calls):
+    if hi:
+        os.environ["AMDR_DENSE_HI"] = hi
+    else:
+        os.environ.pop("AMDR_DENSE_HI", None)
+    idx = _native.DenseIndex(device_ptr=X.data_ptr(), n=n, dim=d, device=0, keepalive=X)
+    idx.reserve(64, 10)
+    s = torch.empty(64, 10, device=dev)
+    i = torch.empty(64, 10, dtype=torch.int64, device=dev)
+    st = int(torch.cuda.current_stream().cuda_stream)
+    outs, t0 = [], time.perf_counter()
+    for c in range(calls):
+        idx.search_device(Q[64 * c:].data_ptr(), 64, 10, s.data_ptr(), i.data_ptr(), st)
+        torch.cuda.synchronize()  # lets the adaptive width see every search's counters
+        outs.append((s.cpu().numpy().copy(), i.cpu().numpy().copy()))
+    ms = (time.perf_counter() - t0) / calls * 1e3
+    cnt = idx.hi_counters()
+    idx.close()
+    return outs, ms, cnt
+
+
+for spread in (float(x) for x in os.environ.get("SPREADS", "1.0,0.5,0.25").split(",")):
+    X = build(spread)
+    cq = torch.randint(0, C, (64 * 16,), device=dev, generator=g)
+    Q = torch.nn.functional.normalize(centres[cq] + 0.7 * torch.randn(64 * 16, d, device=dev, generator=g) / d ** 0.5, dim=1)
+    ex, ms_ex, _ = run(X, Q, "0", 4)
+    hi, ms_hi, cnt = run(X, Q, "1" if os.environ.get("PIN") else "", 16)
+    same = all(np.array_equal(a[1], b[1]) and np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) for a, b in zip(ex, hi))
+    top = float(np.mean([o[0][:, 0].mean() for o in hi])), float(np.mean([o[0][:, 9].mean() for o in hi]))
+    print(json.dumps({"spread": spread, "mean_top1_top10_score": top, "ms_exact": round(ms_ex, 3), "ms_fp16_first_pass": round(ms_hi, 3),
+                      "queries": cnt[0], "unresolved": cnt[1], "level": cnt[2], "in_use": cnt[3], "passes": cnt[4],
+                      "flagged_passes": cnt[5], "identical_on_first_4_calls": same}), flush=True)
+    del X
+    torch.cuda.empty_cache()
