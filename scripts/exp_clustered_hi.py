@@ -39,6 +39,8 @@ def run(X, Q, hi, calls):
     s = torch.empty(64, 10, device=dev)
     i = torch.empty(64, 10, dtype=torch.int64, device=dev)
     st = int(torch.cuda.current_stream().cuda_stream)
+    idx.search_device(Q.data_ptr(), 64, 10, s.data_ptr(), i.data_ptr(), st)  # first-call set-up is not in the timing
+    torch.cuda.synchronize()
     outs, t0 = [], time.perf_counter()
     for c in range(calls):
         idx.search_device(Q[64 * c:].data_ptr(), 64, 10, s.data_ptr(), i.data_ptr(), st)
@@ -54,12 +56,12 @@ for spread in (float(x) for x in os.environ.get("SPREADS", "1.0,0.5,0.25").split
     X = build(spread)
     cq = torch.randint(0, C, (64 * 16,), device=dev, generator=g)
     Q = torch.nn.functional.normalize(centres[cq] + 0.7 * torch.randn(64 * 16, d, device=dev, generator=g) / d ** 0.5, dim=1)
-    ex, ms_ex, _ = run(X, Q, "0", 4)
+    ex, ms_ex, _ = run(X, Q, "0", 8)
     hi, ms_hi, cnt = run(X, Q, "1" if os.environ.get("PIN") else "", 16)
     same = all(np.array_equal(a[1], b[1]) and np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) for a, b in zip(ex, hi))
     top = float(np.mean([o[0][:, 0].mean() for o in hi])), float(np.mean([o[0][:, 9].mean() for o in hi]))
     print(json.dumps({"spread": spread, "mean_top1_top10_score": top, "ms_exact": round(ms_ex, 3), "ms_fp16_first_pass": round(ms_hi, 3),
                       "queries": cnt[0], "unresolved": cnt[1], "level": cnt[2], "in_use": cnt[3], "passes": cnt[4],
-                      "flagged_passes": cnt[5], "identical_on_first_4_calls": same}), flush=True)
+                      "flagged_passes": cnt[5], "identical_on_first_8_calls": same}), flush=True)
     del X
     torch.cuda.empty_cache()
