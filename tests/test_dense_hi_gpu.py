@@ -310,3 +310,35 @@ def test_hi_first_pass_candidate_list_flushes_and_overflow(nat, monkeypatch):
     idx.close()
     assert (took, bad) == (64, 64)
     assert (i == np.arange(10)[None, :]).all() and (s == s[:, :1]).all()
+
+
+def test_hi_first_pass_seeded_sweep_of_shapes(nat, monkeypatch):
+    """Seeded sweep: n, d (every supported width), batch size (1-4 passes of 48 / 64 queries + remainders), k to 100,
+    plain and scaled rows — ids and score bits of the exact two-level form every time."""
+    rng = np.random.default_rng(4242)
+    unresolved = took_total = 0
+    for trial in range(24):
+        d = int(rng.choice([128, 256, 384, 512, 640, 768, 896, 1024]))
+        k = int(rng.choice([1, 2, 5, 10, 17, 40, 100]))
+        kc_max = k + max(k, 96) + 1
+        n = int(rng.integers(64 * kc_max + 1, 64 * kc_max + 40000))
+        nq = int(rng.integers(5, 200))
+        X, Q = unit_rows(rng, n, d), unit_rows(rng, nq, d)
+        if trial % 3 == 1:
+            X *= rng.uniform(0.2, 5.0, size=(n, 1)).astype(np.float32)
+            Q *= np.float32(rng.uniform(1e-3, 1e3))
+        out = {}
+        for name, hi in (("hi", "1"), ("exact", "0")):
+            monkeypatch.setenv("AMDR_DENSE_HI", hi)
+            monkeypatch.setenv("AMDR_DENSE_TWO_LEVEL", "1")
+            idx = nat.DenseIndex(X)
+            out[name] = idx.search(Q, k)
+            if name == "hi":
+                assert "dense_hi_tilemax_kernel" in idx.plan_info(nq, k), (n, d, nq, k)
+                c = idx.hi_counters()
+                took_total += c[0]
+                unresolved += c[1]
+            idx.close()
+        assert np.array_equal(out["hi"][1], out["exact"][1]), (trial, n, d, nq, k)
+        assert np.array_equal(out["hi"][0].view(np.uint32), out["exact"][0].view(np.uint32)), (trial, n, d, nq, k)
+    assert took_total > 1500 and unresolved * 20 < took_total  # the fast path is what ran
