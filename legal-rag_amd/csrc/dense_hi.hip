@@ -440,12 +440,12 @@ static int launch_hi_d(const float* X, long n, int d, const float* Q, int nq, fl
   }
 }
 
-// the sample: every tile_stride-th tile; ~2 048-4 096 of them (a power-of-two stride <= 256), every tile of a short matrix
+// the sample: every s-th tile, at most ONE tile per wave of the persistent grid (256 CUs x 8 waves): the pass is bound by
+// the latency of a wave's own chunk chain, a second tile on some waves doubled it (2 442 tiles: 56 us)
 long dense_hi_sample_stride(long n) {
   const long tiles = (n + 31) / 32;
-  long s = 1;
-  while (s < 256 && tiles / (2 * s) >= 2048) s *= 2;
-  return s;
+  const long s = (tiles + 2047) / 2048;
+  return s < 1 ? 1 : s;
 }
 long dense_hi_sample_items(long n) {
   const long tiles = (n + 31) / 32, s = dense_hi_sample_stride(n);
