@@ -114,7 +114,7 @@ int dense_hi_launch_emit(const float* X, long n, int d, const float* Q, int nq, 
 size_t dense_hi_cand_part_bytes(int m, int kc);
 int dense_hi_launch_cand_topk(const void* cand, const unsigned int* total, size_t cap, int m, int kc, void* part,
                               int* nparts, hipStream_t st);
-int dense_hi_launch_check(const float* vals, const int64_t* ids, int m, int kc1, int k, const float* Q, int d,
+int dense_hi_launch_check(const float* vals, int64_t* ids, int m, int kc1, int k, const float* Q, int d,
                           float row_norm_max, float x_scale, long n_tiles, const unsigned int* total, size_t cap, int* flag,
                           unsigned int* unresolved, hipStream_t st);
 int dense_stats_launch(const float* X, long n, int d, unsigned int* out2, hipStream_t st);

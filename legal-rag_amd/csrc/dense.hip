@@ -596,9 +596,9 @@ void two_level_plan(const amdr_dense* h, int m, int k, int kc, TwoLevelPlan* t) 
   t->cand_rows = hi ? (long)kc * 32 : (long)m * kc * 32;
   dense_mfma_plan(t->cand_rows, h->d, m, k, &t->pass2);
   if (hi) {
-    // a (query, tile) pass is 11.7 us of fp32 matrix time on one SIMD: as few tiles per SIMD as one round of blocks allows
-    const int gx = (kc + 15) / 16;
-    t->pass2.rows_per_block = (long)((kc + gx - 1) / gx) * 32;
+    // a (query, tile) pass is 11.7 us of fp32 matrix time on one SIMD and the check drops the tiles below a query's cut
+    // (~14 of 33 stay): four tiles per block = one per SIMD, blocks beyond a query's list return before staging anything
+    t->pass2.rows_per_block = 4 * 32;
     t->pass2.grid_x = (int)((t->cand_rows + t->pass2.rows_per_block - 1) / t->pass2.rows_per_block);
     t->pass2.grid_y = m;
   }

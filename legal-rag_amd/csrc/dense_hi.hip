@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void dense_stats_kernel(const float* __restric
 __global__ __launch_bounds__(64) void dense_hi_check_kernel(const float* __restrict__ vals, int kc1, int k,
                                                             const float* __restrict__ Q, int d, float row_norm_max,
                                                             float x_scale, int x_exp, long n_tiles,
-                                                            const long long* __restrict__ ids,
+                                                            long long* __restrict__ ids,
                                                             const unsigned int* __restrict__ total, unsigned int cap,
                                                             int* __restrict__ flag, unsigned int* __restrict__ unresolved) {
   const int q = blockIdx.x, lane = threadIdx.x;
@@ -369,7 +369,6 @@ __global__ __launch_bounds__(64) void dense_hi_check_kernel(const float* __restr
   }
 #pragma unroll
   for (int sft = 1; sft < 64; sft <<= 1) ss += __shfl_xor(ss, sft);
-  if (lane != 0) return;
   const float rel = 1.125f * (9.765625e-4f + 2.4e-7f + 2.f * (float)(d + 8) * 5.9604645e-8f);
   const float eps = rel * sqrtf(ss) * (row_norm_max * x_scale) + 1.125f * (float)d * 5.9604645e-8f;
   const bool bad = nan || !(amax <= FLT_MAX) || !(eps == eps) || e + x_exp > 100 || e + x_exp < -100;
@@ -378,14 +377,23 @@ __global__ __launch_bounds__(64) void dense_hi_check_kernel(const float* __restr
   // the flat candidate list overflowed (the sample's threshold let too many maxima pass), or the query has fewer than kc1
   // candidates (a NaN threshold: fewer than kc1 sample tiles with a real maximum): the exact chain decides
   if (*total > cap || ids[(size_t)q * kc1 + kc1 - 1] < 0) raise = true;
+  float cut = -FLT_MAX;
   if (!raise && n_tiles >= kc1) {  // fewer tiles than candidates: every tile is one already
     const float Tk = v[k - 1], last = v[kc1 - 1];
-    raise = !(last < Tk - 2.f * eps);
+    cut = Tk - 2.f * eps;
+    raise = !(last < cut);
   }
-  if (raise) {
-    if (atomicOr(flag, 1) == 0) atomicAdd(unresolved + 1, 1u);  // passes whose flag went up (the first query to raise it)
-    atomicAdd(unresolved, 1u);                                   // queries; both: amdr_dense_hi_counters
+  if (raise) {  // (every lane holds the same values: one lane reports)
+    if (lane == 0) {
+      if (atomicOr(flag, 1) == 0) atomicAdd(unresolved + 1, 1u);  // passes whose flag went up (the first query to raise it)
+      atomicAdd(unresolved, 1u);                                   // queries; both: amdr_dense_hi_counters
+    }
+    return;
   }
+  // Resolved: only the tiles at or above the cut can hold one of the k best rows — the others are dropped from the
+  // query's list (the list is sorted by maximum: a suffix), ~14 of 33 stay at k = 10 and the exact pass scores those.
+  for (int j = lane; j < kc1; j += 64)
+    if (v[j] < cut) ids[(size_t)q * kc1 + j] = -1ll;
 }
 
 // d = 1 024: a 48-query tile (96 KiB; 64 queries + the stages would take all 160 KiB of LDS)
@@ -494,14 +502,14 @@ int dense_hi_launch_transpose(const float* MT, long items, int nq, long ldM, flo
   return AMDR_OK;
 }
 
-int dense_hi_launch_check(const float* vals, const int64_t* ids, int m, int kc1, int k, const float* Q, int d,
+int dense_hi_launch_check(const float* vals, int64_t* ids, int m, int kc1, int k, const float* Q, int d,
                           float row_norm_max, float x_scale, long n_tiles, const unsigned int* total, size_t cap, int* flag,
                           unsigned int* unresolved, hipStream_t st) {
   int x_exp = 0;
   (void)frexpf(x_scale, &x_exp);  // x_scale = 2^-ex = 0.5 * 2^(1 - ex)
   x_exp = 1 - x_exp;
   hipLaunchKernelGGL(dense_hi_check_kernel, dim3(m), dim3(64), 0, st, vals, kc1, k, Q, d, row_norm_max, x_scale, x_exp, n_tiles,
-                     (const long long*)ids, total, (unsigned int)cap, flag, unresolved);
+                     (long long*)ids, total, (unsigned int)cap, flag, unresolved);
   AMDR_HIP(hipGetLastError());
   return AMDR_OK;
 }

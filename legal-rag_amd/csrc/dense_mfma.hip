@@ -158,7 +158,9 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     // with a single LDS tile (gy == 1) nothing is shared between blocks: plain order (a 10 M-row
     // scan measured 1 % slower remapped, the UCC-en launch 1.3 % faster and 3.7x less fabric traffic)
-    const int logical = gy == 1 ? bid : (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    // (mode 3: plain order too — low bx = the head of every query's list = the live blocks; in XCD-contiguous order they
+    // would all land on the first XCDs and the blocks beyond the lists on the last)
+    const int logical = (gy == 1 || mode == 3) ? bid : (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     bx = logical / gy;
     by = logical - bx * gy;
   }
@@ -168,6 +170,14 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
     nq = by + 1;
     tile_list += (size_t)by * list_stride;
     tile_count += by;
+    // a block whose tiles all lie beyond the query's list has nothing to score: its columns can never win
+    const long lo3 = (long)bx * rows_per_block;
+    if ((lo3 >> 5) >= *tile_count) {
+      long hi3 = lo3 + rows_per_block;
+      if (hi3 > n) hi3 = n;
+      for (long c = lo3 + threadIdx.x; c < hi3; c += WAVES * 64) S[(size_t)by * ldS + c] = -FLT_MAX;
+      return;
+    }
   }
 
   // ---- stage the query tile, row-major with a per-row XOR swizzle of the 16-byte slots:
