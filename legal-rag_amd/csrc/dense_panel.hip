@@ -28,6 +28,7 @@
 // c and retired (vmcnt(0)) at the block barrier that ends chunk c.
 #include "common.hpp"
 
+#include <atomic>
 #include <cstdlib>
 
 namespace amdr {
@@ -268,20 +269,22 @@ static int launch_panel(const DensePanelPlan& p, const float* X, long n, int d, 
   int grid = p.m_tiles * p.parts;
   const char* pe = getenv("AMDR_PANEL_PERSIST");
   if (!(pe && pe[0] == '0')) {
-    // (device, NB) -> resident blocks per CU x CUs, asked once per process and device (a benign race writes the
-    // same value twice)
-    static int resident_cache[64] = {0};
+    // (device, NB) -> resident blocks per CU x CUs, asked once per process and device (two threads that race here
+    // store the same value; the slot is an atomic so that neither reads a torn one)
+    static std::atomic<int> resident_cache[64];
     int dev = 0, cus = 0, per_cu = 0;
     AMDR_HIP(hipGetDevice(&dev));
     const int slot = dev & 63;
-    if (resident_cache[slot] == 0) {
+    int cached = resident_cache[slot].load(std::memory_order_relaxed);
+    if (cached == 0) {
       AMDR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
       AMDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dense_panel_scores_kernel<NB, kPanelWaves>,
                                                             kPanelWaves * 64, p.lds));
-      resident_cache[slot] = (per_cu << 16) | (cus & 0xffff);
+      cached = (per_cu << 16) | (cus & 0xffff);
+      resident_cache[slot].store(cached, std::memory_order_relaxed);
     }
-    per_cu = resident_cache[slot] >> 16;
-    cus = resident_cache[slot] & 0xffff;
+    per_cu = cached >> 16;
+    cus = cached & 0xffff;
     if (pe && atoi(pe) >= 1) per_cu = atoi(pe);
     const int resident = per_cu * cus / 8 * 8;
     if (resident >= 8 && grid > resident) grid = resident;
