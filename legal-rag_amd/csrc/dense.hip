@@ -1167,8 +1167,9 @@ int amdr_dense_plan_info(const amdr_dense_t* h, int32_t nq, int32_t k, char* buf
     snprintf(buf, buf_len,
              "dense_hi_tilemax_kernel fp16 first pass queries_per_launch=%d two-level: top-%d of %ld approximate tile "
              "maxima (width level %d; threshold from a sample of every %ld-th tile), cut checked against the rounding bound "
-             "+ exact re-scoring of <= %d candidate tiles + top-k (exact first pass behind a device flag)",
-             m, kc, t.tiles, hi_level_of(h), dense_hi_sample_stride((long)h->n), m * kc);
+             "+ exact re-scoring of every query's tiles at or above its cut (<= %d each) + top-k (exact first pass behind a "
+             "device flag)",
+             m, kc, t.tiles, hi_level_of(h), dense_hi_sample_stride((long)h->n), kc);
     return AMDR_OK;
   }
   if (hi_applies(h, nq, k)) {  // the handle gave the fp16 pass up: exact passes in the same shapes
