@@ -985,6 +985,10 @@ def main():
                 result["hbm_scan"] = run_hbm_scan(torch, device, a.synth_rows, 768, [4, 32, 64], steps=20, warmup=3)
             except Exception as e:  # noqa: BLE001 - report, never hide
                 result["hbm_scan"] = {"error": repr(e)}
+            try:  # the other width north_star names (BGE-large / M3): d = 1 024, 48 queries per scan (LDS), same bytes
+                result["hbm_scan_d1024"] = run_hbm_scan(torch, device, int(a.synth_rows * 0.75), 1024, [48], steps=10, warmup=2)
+            except Exception as e:  # noqa: BLE001
+                result["hbm_scan_d1024"] = {"error": repr(e)}
     else:
         sc = run_scale_synth10m(torch, dist, world, rank, local, device, a.synth_rows, a.synth_batch, a.steps, a.warmup)
         result = {"metric": "queries/sec, brute-force cosine top-10", "value": sc["value"], "unit": "queries/s",
