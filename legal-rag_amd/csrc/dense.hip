@@ -973,6 +973,11 @@ int amdr_dense_add(amdr_dense_t* h, const float* X_host, int64_t n_add) {
   AMDR_HIP(hipMemcpy(h->X + (size_t)h->n * h->d, X_host, (size_t)n_add * h->d * sizeof(float), hipMemcpyHostToDevice));
   const int64_t row0 = h->n;
   h->n += n_add;
+  // the matrix changed: what the fp16 first pass learnt about it (width level, given up) starts over
+  h->hi_level = 0;
+  h->hi_off = false;
+  h->lvl_p0 = h->hi_passes;
+  if (h->hi_host) h->lvl_f0 = ((volatile unsigned int*)h->hi_host)[1];
   return update_stats(h, row0, n_add);
 }
 
