@@ -675,6 +675,7 @@ def _hbm_scan_one(torch, _native, device, X, Q, n, d, B, steps, warmup, k):
         # the FULL matrix; and how many queries its rounding bound could not resolve (their batches also ran the exact pass)
         took, unresolved, level, in_use, passes, flagged = idx.hi_counters()
         hs, hids = s.cpu().numpy().copy(), i.cpu().numpy().copy()
+        prev_hi = os.environ.get("AMDR_DENSE_HI")  # a pin the caller supplied (A/B scripts) survives this check
         os.environ["AMDR_DENSE_HI"] = "0"
         try:
             ex = _native.DenseIndex(device_ptr=X.data_ptr(), n=n, dim=d, device=device.index, keepalive=X)
@@ -685,7 +686,10 @@ def _hbm_scan_one(torch, _native, device, X, Q, n, d, B, steps, warmup, k):
                         np.array_equal(es_.cpu().numpy().view(np.uint32), hs.view(np.uint32)))
             ex.close()
         finally:
-            del os.environ["AMDR_DENSE_HI"]
+            if prev_hi is None:
+                os.environ.pop("AMDR_DENSE_HI", None)
+            else:
+                os.environ["AMDR_DENSE_HI"] = prev_hi
         extra = {"fp16_first_pass": {"queries": took, "unresolved_by_the_rounding_bound": unresolved,
                                      "full_matrix_ids_and_score_bits_equal_exact_first_pass": same,
                                      "queries_per_scan": per_scan, "width_level": level, "in_use": in_use,

@@ -63,7 +63,9 @@ int amdr_device_name(int32_t device, char* buf, int32_t buf_len); /* gcnArchName
  * score -FLT_MAX when k > n (faiss convention). */
 int amdr_dense_create(const float* X_host, int64_t n, int32_t d, int32_t device, amdr_dense_t** out);
 /* adopt an existing device matrix without copying (the caller keeps ownership
- * and must keep it alive); used for shards generated in HBM */
+ * and must keep it alive); used for shards generated in HBM.  The matrix is READ at creation (largest component and
+ * row norm, for the fp16 first pass of large scans): the call synchronises the device first, so work that fills X on
+ * any stream and was enqueued before the call is complete; the matrix must not change while the handle lives. */
 int amdr_dense_create_from_device(const float* X_dev, int64_t n, int32_t d, int32_t device, amdr_dense_t** out);
 int amdr_dense_add(amdr_dense_t* h, const float* X_host, int64_t n_add);
 int amdr_dense_ntotal(const amdr_dense_t* h, int64_t* n);
@@ -259,6 +261,30 @@ int amdr_merge_topk_f32_device(const float* scores, const int64_t* ids, int32_t 
                                int32_t k_out, float* out_scores, int64_t* out_ids, int32_t device, void* stream);
 int amdr_merge_topk_f64_device(const double* scores, const int64_t* ids, int32_t n_parts, int32_t nq, int32_t k_in,
                                int32_t k_out, double* out_scores, int64_t* out_ids, int32_t device, void* stream);
+
+/* ---- multi-GPU: the shard exchange of ALL channels, one launch either side of the all-gather -------------------
+ * No reference counterpart (single process; legalrag/config.py:106 `colbert_nranks = 1`).  SURVEY.md 8(b)/8(e):
+ * rank r holds rows [offset_r, offset_r + n_r) of every channel; per query batch ONE all-gather of a packed int64
+ * buffer carries every channel's per-shard top-k.
+ *   row of query q (amdr_shard_row_words words) = for each channel c, in order:
+ *       k_c score words (the score's bits as fp64; an fp32 score widens exactly) | k_c GLOBAL ids (-1 = padding)
+ * amdr_shard_pack_device : this rank's lists (scores fp32 or fp64 [nq, k_c], LOCAL ids [nq, k_c]) -> send [nq, row];
+ *                          global id = local id + id_offset.
+ * amdr_shard_merge_device: gathered [world, nq, row] (the all-gather's output, read in place) -> per channel the global
+ *                          top-k_c: out scores [nq, k_c] (fp32 / fp64 as flagged), out ids [nq, k_c]; score descending,
+ *                          ties -> lower global id, -1 / -FLT_MAX (-DBL_MAX) padding.  Identical on every rank.
+ * Both only enqueue on `stream` (graph-capturable); up to 4 channels, k_c <= AMDR_MAX_K. */
+typedef struct amdr_shard_chan {
+  void* scores;   /* pack: const input lists; merge: output */
+  int64_t* ids;
+  int32_t k;
+  int32_t f64;    /* 1: scores are double (BM25), 0: float (dense, MaxSim) */
+} amdr_shard_chan_t;
+int amdr_shard_row_words(const amdr_shard_chan_t* chans, int32_t n_chan, int64_t* words);
+int amdr_shard_pack_device(const amdr_shard_chan_t* chans, int32_t n_chan, int32_t nq, int64_t id_offset, int64_t* send,
+                           int32_t device, void* stream);
+int amdr_shard_merge_device(const int64_t* gathered, int32_t world, int32_t nq, const amdr_shard_chan_t* out_chans,
+                            int32_t n_chan, int32_t device, void* stream);
 
 #ifdef __cplusplus
 }

@@ -38,6 +38,7 @@ EXPORTS = (
     "amdr_maxsim_search_device", "amdr_maxsim_scores", "amdr_maxsim_destroy",
     "amdr_fuse", "amdr_fuse_device", "amdr_rerank_blend", "amdr_rerank_blend_device",
     "amdr_merge_topk_f32_device", "amdr_merge_topk_f64_device",
+    "amdr_shard_row_words", "amdr_shard_pack_device", "amdr_shard_merge_device",
 )
 
 
@@ -62,6 +63,7 @@ SIGNATURES = {
     "amdr_fuse": "Pi" + "PPi" * 3 + "PPPP", "amdr_fuse_device": "Pi" + "PPiP" * 3 + "PPPP" + "iP",
     "amdr_rerank_blend": "iiPPPPPidP", "amdr_rerank_blend_device": "iiPPPPPidPiP",
     "amdr_merge_topk_f32_device": "PPiiiiPPiP", "amdr_merge_topk_f64_device": "PPiiiiPPiP",
+    "amdr_shard_row_words": "PiP", "amdr_shard_pack_device": "PiilPiP", "amdr_shard_merge_device": "PiiPiiP",
 }
 _KIND = {"P": C.c_void_p, "i": C.c_int32, "l": C.c_int64, "d": C.c_double}
 
@@ -73,6 +75,11 @@ class NativeError(RuntimeError):
 class FuseParams(C.Structure):
     _fields_ = [("method", C.c_int32), ("rrf_k", C.c_int32), ("alpha", C.c_double), ("w_dense", C.c_double),
                 ("w_bm25", C.c_double), ("w_colbert", C.c_double), ("min_final_score", C.c_double)]
+
+
+class ShardChan(C.Structure):
+    """amdr_shard_chan_t: one channel of the shard exchange (device pointers)."""
+    _fields_ = [("scores", C.c_void_p), ("ids", C.c_void_p), ("k", C.c_int32), ("f64", C.c_int32)]
 
 
 _lib: Optional[C.CDLL] = None
@@ -555,3 +562,34 @@ def merge_topk_device(scores: int, ids: int, n_parts: int, nq: int, k_in: int, k
     fn = load().amdr_merge_topk_f64_device if f64 else load().amdr_merge_topk_f32_device
     _check(fn(_vp(scores), _vp(ids), C.c_int32(n_parts), C.c_int32(nq), C.c_int32(k_in), C.c_int32(k_out),
               _vp(out_scores), _vp(out_ids), C.c_int32(device), _vp(stream)), "amdr_merge_topk_device")
+
+
+# ---------------------------------------------------------------------------
+def _shard_chans(chans):
+    """[(scores_ptr, ids_ptr, k, is_f64)] -> (amdr_shard_chan_t array, n)."""
+    arr = (ShardChan * len(chans))()
+    for c, (sp, ip, k, f64) in zip(arr, chans):
+        c.scores, c.ids, c.k, c.f64 = int(sp) if sp else None, int(ip) if ip else None, int(k), 1 if f64 else 0
+    return arr, len(chans)
+
+
+def shard_row_words(ks: Sequence[int]) -> int:
+    """int64 words per query row of the packed exchange buffer: sum of 2 * k_c."""
+    arr, n = _shard_chans([(0, 0, k, False) for k in ks])
+    w = C.c_int64(0)
+    _check(load().amdr_shard_row_words(arr, C.c_int32(n), C.byref(w)), "amdr_shard_row_words")
+    return int(w.value)
+
+
+def shard_pack_device(chans, nq: int, id_offset: int, send_ptr: int, *, device: int = 0, stream: int = 0) -> None:
+    """chans: [(scores_ptr, local_ids_ptr, k, is_f64)] of this rank -> send [nq, row] (ONE launch, all channels)."""
+    arr, n = _shard_chans(chans)
+    _check(load().amdr_shard_pack_device(arr, C.c_int32(n), C.c_int32(nq), C.c_int64(id_offset), _vp(send_ptr),
+                                         C.c_int32(device), _vp(stream)), "amdr_shard_pack_device")
+
+
+def shard_merge_device(gathered_ptr: int, world: int, nq: int, out_chans, *, device: int = 0, stream: int = 0) -> None:
+    """gathered [world, nq, row] -> out_chans [(out_scores_ptr, out_ids_ptr, k, is_f64)] (ONE launch, all channels)."""
+    arr, n = _shard_chans(out_chans)
+    _check(load().amdr_shard_merge_device(_vp(gathered_ptr), C.c_int32(world), C.c_int32(nq), arr, C.c_int32(n),
+                                          C.c_int32(device), _vp(stream)), "amdr_shard_merge_device")

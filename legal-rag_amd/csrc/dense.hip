@@ -945,6 +945,10 @@ int amdr_dense_create_from_device(const float* X_dev, int64_t n, int32_t d, int3
     amdr_dense_destroy(h);
     return fail(AMDR_EHIP, "dense_create_from_device: %s", hipGetErrorString(e));
   }
+  // The statistics kernel runs on the handle's own (non-blocking) stream: whatever produced X on ANOTHER stream must
+  // have finished first, or the largest component / row norm — the fp16 first pass's error bound — would be taken from
+  // a half-written matrix.  Creation is synchronous anyway: wait for the device.
+  AMDR_HIP(hipDeviceSynchronize());
   if ((rc = update_stats(h, 0, n))) {  // the wrapped matrix must not change while the handle lives
     amdr_dense_destroy(h);
     return rc;

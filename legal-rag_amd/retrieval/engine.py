@@ -191,7 +191,7 @@ class HybridEngine:
         if self.shard_offset is not None:
             from . import sharding
             chans = [x for x in (d, b, c) if x is not None]
-            merged = iter(sharding.exchange_topk(chans, int(self.shard_offset), group=self.shard_group))
+            merged = iter(sharding.exchange_topk(chans, int(self.shard_offset), group=self.shard_group, buf=self._buf))
             d, b, c = (next(merged) if x is not None else None for x in (d, b, c))
         res = self.fuse(params, nq, d, b, c)
         if d is not None:

@@ -559,6 +559,10 @@ class HybridRetriever:
                 q_tok_h = np.stack([np.asarray(col._encoder.encode_query((q or "").strip()), dtype=np.float32)
                                     for q in questions])
             except Exception:  # noqa: BLE001 - the reference swallows ColBERT channel errors (:244-245)
+                if getattr(store.index, "spec", None) is not None:
+                    # row-sharded: dropping the channel is a rank-LOCAL decision inside an SPMD exchange — the other ranks
+                    # would all-gather three packed channels against this rank's two (hang, or garbage).  Fail loudly.
+                    raise
                 col, q_tok_h = None, None
         t3 = time.time()
         kn = self._knobs()
@@ -579,8 +583,8 @@ class HybridRetriever:
                 res = eng.search_batch(self._params(kn, min_final), eff, q_emb=q_emb, q_terms=q_terms_d, q_ptr=q_ptr_d,
                                        q_tok=torch.from_numpy(q_tok_h).to(tdev, non_blocking=True) if q_tok_h is not None else None)
             except _native.NativeError:
-                if col is None:
-                    raise
+                if col is None or eng.shard_offset is not None:
+                    raise  # (row-sharded: a rank must not leave the common exchange on its own, see above)
                 # a failing ColBERT stage (e.g. out of memory) empties that channel, it does not fail the query
                 # (hybrid_retriever.py:244-245, colbert_retriever.py:171-181); a dense / BM25 failure raises again here
                 eng = engines.get(False)
