@@ -565,8 +565,8 @@ def merge_topk_device(scores: int, ids: int, n_parts: int, nq: int, k_in: int, k
 
 
 # ---------------------------------------------------------------------------
-def _shard_chans(chans):
-    """[(scores_ptr, ids_ptr, k, is_f64)] -> (amdr_shard_chan_t array, n)."""
+def shard_chans(chans):
+    """[(scores_ptr, ids_ptr, k, is_f64)] -> (amdr_shard_chan_t array, n): the argument block of the shard calls."""
     arr = (ShardChan * len(chans))()
     for c, (sp, ip, k, f64) in zip(arr, chans):
         c.scores, c.ids, c.k, c.f64 = int(sp) if sp else None, int(ip) if ip else None, int(k), 1 if f64 else 0
@@ -575,21 +575,27 @@ def _shard_chans(chans):
 
 def shard_row_words(ks: Sequence[int]) -> int:
     """int64 words per query row of the packed exchange buffer: sum of 2 * k_c."""
-    arr, n = _shard_chans([(0, 0, k, False) for k in ks])
+    arr, n = shard_chans([(0, 0, k, False) for k in ks])
     w = C.c_int64(0)
     _check(load().amdr_shard_row_words(arr, C.c_int32(n), C.byref(w)), "amdr_shard_row_words")
     return int(w.value)
 
 
+def shard_pack_args(args, nq: int, id_offset: int, send_ptr: int, *, device: int = 0, stream: int = 0) -> None:
+    _check(load().amdr_shard_pack_device(args[0], args[1], nq, id_offset, send_ptr, device, stream),
+           "amdr_shard_pack_device")
+
+
+def shard_merge_args(gathered_ptr: int, world: int, nq: int, args, *, device: int = 0, stream: int = 0) -> None:
+    _check(load().amdr_shard_merge_device(gathered_ptr, world, nq, args[0], args[1], device, stream),
+           "amdr_shard_merge_device")
+
+
 def shard_pack_device(chans, nq: int, id_offset: int, send_ptr: int, *, device: int = 0, stream: int = 0) -> None:
     """chans: [(scores_ptr, local_ids_ptr, k, is_f64)] of this rank -> send [nq, row] (ONE launch, all channels)."""
-    arr, n = _shard_chans(chans)
-    _check(load().amdr_shard_pack_device(arr, C.c_int32(n), C.c_int32(nq), C.c_int64(id_offset), _vp(send_ptr),
-                                         C.c_int32(device), _vp(stream)), "amdr_shard_pack_device")
+    shard_pack_args(shard_chans(chans), nq, id_offset, send_ptr, device=device, stream=stream)
 
 
 def shard_merge_device(gathered_ptr: int, world: int, nq: int, out_chans, *, device: int = 0, stream: int = 0) -> None:
     """gathered [world, nq, row] -> out_chans [(out_scores_ptr, out_ids_ptr, k, is_f64)] (ONE launch, all channels)."""
-    arr, n = _shard_chans(out_chans)
-    _check(load().amdr_shard_merge_device(_vp(gathered_ptr), C.c_int32(world), C.c_int32(nq), arr, C.c_int32(n),
-                                          C.c_int32(device), _vp(stream)), "amdr_shard_merge_device")
+    shard_merge_args(gathered_ptr, world, nq, shard_chans(out_chans), device=device, stream=stream)

@@ -118,6 +118,25 @@ int dense_hi_launch_check(const float* vals, int64_t* ids, int m, int kc1, int k
                           float row_norm_max, float x_scale, long n_tiles, const unsigned int* total, size_t cap, int* flag,
                           unsigned int* unresolved, hipStream_t st);
 int dense_stats_launch(const float* X, long n, int d, unsigned int* out2, hipStream_t st);
+// round 4: the tail of a large search in four launches + two gated ones (dense_hi.hip, dense_mfma.hip)
+long dense_hi2_sample_stride(long n, int qtiles);
+long dense_hi2_sample_items(long n, int qtiles);
+size_t dense_hi2_qcap(long n, int qtiles, int kc);
+int dense_hi2_launch_sample(const float* X, long n, int d, const float* Q, int nq, int qtiles, float* MT, hipStream_t st,
+                            float x_scale);
+int dense_hi2_launch_tau(const float* MT, long n, int d, int nq, int qtiles, int kc, float* tau, unsigned int* qcount,
+                         int* flag, unsigned int* stats, hipStream_t st);
+int dense_hi2_launch_emit(const float* X, long n, int d, const float* Q, int nq, const float* tau, void* qlist,
+                          unsigned int* qcount, size_t qcap, hipStream_t st, float x_scale);
+int dense_hi2_launch_select(const void* qlist, const unsigned int* qcount, size_t qcap, int m, int kc, int k, const float* Q,
+                            int d, float row_norm_max, float x_scale, long n_tiles, int* list, int* count, int* unres,
+                            int* flag, unsigned int* unresolved, hipStream_t st);
+int dense_hi2_launch_exact_select(const float* M, long ldM, long n_tiles, int m, int k, int list_stride, int* list, int* count,
+                                  const int* unres, const int* gate, hipStream_t st);
+int dense_rescore_tiles_launch(const float* X, long n_real, int d, const float* Q, int m, const int* list, const int* count,
+                               int list_stride, int max_tiles, long ldS, float* S, hipStream_t st);
+int dense_final_topk_launch(const float* S, long ldS, const int* list, const int* count, int list_stride, int max_tiles,
+                            long n_real, int m, int k, float* fin_scores, int64_t* fin_ids, hipStream_t st);
 
 
 // ---- dense top-k + fusion in one call (fuse.hip; dense.hip amdr_dense_search_fuse_device) ----

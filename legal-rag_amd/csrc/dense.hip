@@ -322,7 +322,10 @@ struct amdr_dense {
   int64_t hi_passes = 0;        // passes (<= 64 queries each) through the fp16 first pass
   int64_t lvl_p0 = 0;           // hi_passes / flagged-pass counter when the current level was entered
   unsigned int lvl_f0 = 0;
-  unsigned int* hi_host = nullptr;  // pinned: the device's (unresolved queries, flagged passes), copied back after every search
+  unsigned int* hi_host = nullptr;  // pinned: the device's (unresolved queries, flagged passes, passes), copied back after every search
+  hipEvent_t hi_ev = nullptr;       // recorded behind that copy: hi_adapt reads hi_host only once it has completed
+  bool hi_copy_pending = false;
+  unsigned int hi_seen[3] = {0u, 0u, 0u};  // the last completed copy
   // optional HIP-event ring bracketing the scan kernel alone (bench.py roofline)
   std::vector<hipEvent_t> prof_ev;
   int prof_used = 0;
@@ -555,10 +558,21 @@ int hi_chunk(const amdr_dense* h, int nq, int k) {  // the same at every level: 
 // unresolved query sends its whole pass through the exact chain as well (+2 scans for a 1-scan pass), so what is
 // counted is PASSES whose flag went up: more than 10 % of >= 4 passes at this width -> the next width (+3 % per pass);
 // at the widest, more than half -> the exact passes alone are cheaper (1 + 2 f > 2).
+bool hi_tail2();
 void hi_adapt(amdr_dense* h) {
   if (!h->hi_host || h->hi_off || getenv("AMDR_DENSE_HI_LEVEL")) return;
-  const unsigned int f = ((volatile unsigned int*)h->hi_host)[1];
-  const int64_t p = h->hi_passes - h->lvl_p0;
+  // the counters are whatever the last COMPLETED copy-back left: the pinned words are read only after the event behind
+  // their copy has been reached (round 3 read them while a copy could still be in flight)
+  if (h->hi_copy_pending) {
+    if (hipEventQuery(h->hi_ev) != hipSuccess) return;  // still on its way: adapt at the next search
+    h->hi_copy_pending = false;
+    for (int i = 0; i < 3; ++i) h->hi_seen[i] = h->hi_host[i];
+  }
+  const unsigned int f = h->hi_seen[1];
+  // passes: counted on the device next to the flags under the round-4 tail (a hipGraph replay bumps both; the host's
+  // own count would not see replays), on the host under the round-3 tail
+  const int64_t passes = hi_tail2() ? (int64_t)h->hi_seen[2] : h->hi_passes;
+  const int64_t p = passes - h->lvl_p0;
   const int64_t bad = (int64_t)(f - h->lvl_f0);
   if (p < 4) return;
   bool move = false;
@@ -571,9 +585,52 @@ void hi_adapt(amdr_dense* h) {
     if (move) h->hi_off = true;
   }
   if (move || p >= (1 << 16)) {  // a new window
-    h->lvl_p0 = h->hi_passes;
+    h->lvl_p0 = passes;
     h->lvl_f0 = f;
   }
+}
+// AMDR_DENSE_HI_TAIL=0 pins the round-3 tail (flat candidate list, ~18 launches per 64-query pass): A/B, tests
+bool hi_tail2() {
+  const char* e = getenv("AMDR_DENSE_HI_TAIL");
+  return !(e && e[0] == '0');
+}
+constexpr int kHi2Tiles = 4;  // query tiles per pass of the round-4 tail: 256 queries (192 at d = 1 024) share one tail
+int hi2_chunk(const amdr_dense* h, int nq) {
+  const int c = kHi2Tiles * dense_hi_max_queries(h->d);
+  return nq < c ? nq : c;
+}
+
+// Workspace of one pass of the round-4 tail.  smat: exact tile maxima M [m][ldM] (written only when the flag goes up) |
+// re-scored columns S2 [m][32 kc] | sample maxima MT [qtiles][items][64] | per-query candidate lists [m][qcap];
+// aux: list [m][kc] | count, unres [m] | tau [m] | qcount [m] (the gate flag sits at the end of aux, as before).
+struct Hi2Plan {
+  int qtiles, kc;
+  long tiles, ldM, ldS2;
+  size_t qcap;
+  DenseMfmaPlan scan;
+  size_t off_S2, off_MT, off_qlist, smat_bytes;
+  size_t off_count, off_unres, off_tau, off_qcount, aux_bytes;
+};
+void hi2_plan(const amdr_dense* h, int m, int k, int kc, Hi2Plan* p) {
+  auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+  const int qt = dense_hi_max_queries(h->d);
+  p->qtiles = (m + qt - 1) / qt;
+  p->kc = kc;
+  p->tiles = ((long)h->n + 31) / 32;
+  dense_mfma_plan((long)h->n, h->d, m, k, &p->scan);
+  p->ldM = (p->tiles + 31) / 32 * 32;
+  p->scan.ld = p->ldM;
+  p->ldS2 = (long)kc * 32;
+  p->qcap = dense_hi2_qcap((long)h->n, p->qtiles, kc);
+  p->off_S2 = up((size_t)m * p->ldM * sizeof(float));
+  p->off_MT = p->off_S2 + up((size_t)m * p->ldS2 * sizeof(float));
+  p->off_qlist = p->off_MT + up((size_t)(2048 + 64) * 64 * sizeof(float));  // qtiles x items <= 2 048 + 8 qtiles
+  p->smat_bytes = p->off_qlist + up((size_t)m * p->qcap * sizeof(C32));
+  p->off_count = up((size_t)m * kc * sizeof(int));
+  p->off_unres = p->off_count + up((size_t)m * sizeof(int));
+  p->off_tau = p->off_unres + up((size_t)m * sizeof(int));
+  p->off_qcount = p->off_tau + up((size_t)m * sizeof(float));
+  p->aux_bytes = p->off_qcount + up((size_t)m * sizeof(unsigned int));
 }
 
 struct TwoLevelPlan {
@@ -635,8 +692,15 @@ void two_level_need_exact(const amdr_dense* h, int nq, int k, TwoLevelNeed* need
     need->add(t);
   }
 }
+void hi2_need(const amdr_dense* h, int nq, int k, TwoLevelNeed* need) {  // monotone in the pass size and in kc
+  Hi2Plan p;
+  hi2_plan(h, hi2_chunk(h, nq), k, hi_kc_max(k), &p);
+  need->smat = p.smat_bytes > need->smat ? p.smat_bytes : need->smat;
+  need->aux = p.aux_bytes + 256 > need->aux ? p.aux_bytes + 256 : need->aux;
+}
 void two_level_need(const amdr_dense* h, int nq, int k, TwoLevelNeed* need) {
   if (!hi_applies(h, nq, k)) return two_level_need_exact(h, nq, k, need);
+  if (hi_tail2()) hi2_need(h, nq, k, need);
   const int chunk = hi_chunk(h, nq, k);
   TwoLevelPlan t;
   for (int m : {chunk, nq % chunk}) {
@@ -658,6 +722,7 @@ int two_level_ensure(amdr_dense* h, int ws, int nq, int k, bool all = false) {
       // all run the two-level form: cover every m a pass can have
       const bool hi = hi_applies(h, nq, kk);
       if (!hi && !two_level_applies(h, nq < 95 ? nq : 95, kk) && !two_level_applies(h, nq, kk)) continue;
+      if (hi && hi_tail2()) hi2_need(h, nq, kk, &need);
       TwoLevelPlan t;
       if (hi)
         for (int m = 1; m <= hi_chunk(h, nq, kk); ++m)
@@ -778,13 +843,63 @@ int two_level_pass(amdr_dense* h, int ws, const float* Qc, int m, int k, int kc_
   return dense_tiles_remap_launch(out_ids, m * k, list, count, (long)h->n, st, gate);
 }
 
+// One pass (<= 4 query tiles) of the round-4 tail: see dense_hi.hip.  Launches: sample, tau, one scan per query tile,
+// select, [gated: exact tile maxima, exact select], re-scoring, final top-k.
+int hi2_pass(amdr_dense* h, int ws, const float* Qc, int m, int k, int kc, float* out_scores, int64_t* out_ids, hipStream_t st,
+             int* flag) {
+  Hi2Plan p;
+  hi2_plan(h, m, k, kc, &p);
+  unsigned char* sm = reinterpret_cast<unsigned char*>(h->smat[ws].p);
+  unsigned char* ax = reinterpret_cast<unsigned char*>(h->aux[ws].p);
+  float* M = reinterpret_cast<float*>(sm);
+  float* S2 = reinterpret_cast<float*>(sm + p.off_S2);
+  float* MT = reinterpret_cast<float*>(sm + p.off_MT);
+  C32* qlist = reinterpret_cast<C32*>(sm + p.off_qlist);
+  int* list = reinterpret_cast<int*>(ax);
+  int* count = reinterpret_cast<int*>(ax + p.off_count);
+  int* unres = reinterpret_cast<int*>(ax + p.off_unres);
+  float* tau = reinterpret_cast<float*>(ax + p.off_tau);
+  unsigned int* qcount = reinterpret_cast<unsigned int*>(ax + p.off_qcount);
+  unsigned int* stats = h->stats.as<unsigned int>();
+  const int qt = dense_hi_max_queries(h->d);
+  int rc;
+  if ((rc = dense_hi2_launch_sample(h->X, (long)h->n, h->d, Qc, m, p.qtiles, MT, st, h->x_scale))) return rc;
+  if ((rc = dense_hi2_launch_tau(MT, (long)h->n, h->d, m, p.qtiles, kc, tau, qcount, flag, stats, st))) return rc;
+  for (int y = 0; y < p.qtiles; ++y) {
+    const int q0 = y * qt, mq = m - q0 < qt ? m - q0 : qt;
+    const bool prof = h->prof_on && (size_t)(h->prof_used + 2) <= h->prof_ev.size();
+    if (prof) AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
+    if ((rc = dense_hi2_launch_emit(h->X, (long)h->n, h->d, Qc + (size_t)q0 * h->d, mq, tau + q0, qlist + (size_t)q0 * p.qcap,
+                                    qcount + q0, p.qcap, st, h->x_scale)))
+      return rc;
+    if (prof) {
+      AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
+      h->prof_used += 2;
+    }
+  }
+  h->hi_queries += m;
+  h->hi_passes += p.qtiles;
+  if ((rc = dense_hi2_launch_select(qlist, qcount, p.qcap, m, kc, k, Qc, h->d, h->row_norm_max, h->x_scale, p.tiles, list,
+                                    count, unres, flag, stats + 2, st)))
+    return rc;
+  // behind the flag: the exact first pass of the batch and, for the queries the bound did not resolve, their k tiles
+  if ((rc = dense_mfma_launch_scores(p.scan, h->X, (long)h->n, h->d, Qc, m, M, st, 1, nullptr, nullptr, 0, flag))) return rc;
+  if ((rc = dense_hi2_launch_exact_select(M, p.ldM, p.tiles, m, k, kc, list, count, unres, flag, st))) return rc;
+  if ((rc = dense_rescore_tiles_launch(h->X, (long)h->n, h->d, Qc, m, list, count, kc, kc, p.ldS2, S2, st))) return rc;
+  return dense_final_topk_launch(S2, p.ldS2, list, count, kc, kc, (long)h->n, m, k, out_scores, out_ids, st);
+}
+
 int run_search_two_level(amdr_dense* h, int ws, const float* Q_dev, int nq, int k, float* scores_dev, int64_t* ids_dev,
                          hipStream_t st) {
   int rc = two_level_ensure(h, ws, nq, k);
   if (rc) return rc;
   const bool hi = hi_applies(h, nq, k);
-  if (hi) hi_adapt(h);
-  const int chunk = hi ? hi_chunk(h, nq, k) : two_level_chunk(nq, k);
+  hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &cap_st);
+  const bool capturing = cap_st != hipStreamCaptureStatusNone;
+  if (hi && !capturing) hi_adapt(h);
+  const bool tail2 = hi && hi_tail2() && !h->hi_off;
+  const int chunk = tail2 ? hi2_chunk(h, nq) : hi ? hi_chunk(h, nq, k) : two_level_chunk(nq, k);
   const int kc_hi = hi && !h->hi_off ? hi_kc(k, hi_level_of(h)) : 0;
   // the gate flag: behind the largest list layout of this call (two_level_ensure sized aux for it)
   int* flag = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(h->aux[ws].p) + h->aux[ws].cap - 256);
@@ -795,6 +910,10 @@ int run_search_two_level(amdr_dense* h, int ws, const float* Q_dev, int nq, int 
     int64_t* oi = ids_dev + (size_t)q0 * k;
     if (!hi) {
       if ((rc = two_level_pass(h, ws, Qc, m, k, 0, os, oi, st, nullptr, nullptr))) return rc;
+      continue;
+    }
+    if (tail2) {  // (the flag is reset by the pass's own tau kernel)
+      if ((rc = hi2_pass(h, ws, Qc, m, k, kc_hi, os, oi, st, flag))) return rc;
       continue;
     }
     if (kc_hi) {
@@ -811,8 +930,11 @@ int run_search_two_level(amdr_dense* h, int ws, const float* Q_dev, int nq, int 
         return rc;
     }
   }
-  if (kc_hi && h->hi_host)  // what hi_adapt reads before the next search
-    AMDR_HIP(hipMemcpyAsync(h->hi_host, h->stats.as<unsigned int>() + 2, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+  if (kc_hi && h->hi_host && !capturing && !h->hi_copy_pending) {  // what hi_adapt reads before a later search
+    AMDR_HIP(hipMemcpyAsync(h->hi_host, h->stats.as<unsigned int>() + 2, 3 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+    AMDR_HIP(hipEventRecord(h->hi_ev, st));
+    h->hi_copy_pending = true;
+  }
   return AMDR_OK;
 }
 
@@ -869,12 +991,14 @@ int check_search_args(const amdr_dense* h, const void* Q, int nq, int k, const v
 int update_stats(amdr_dense* h, int64_t row0, int64_t rows) {
   h->hi_ok = false;
   if (!dense_hi_supported(h->d)) return AMDR_OK;
-  int rc = h->stats.ensure(4 * sizeof(unsigned int));  // max |x|, max row norm, unresolved queries (counter), pad
+  // max |x|, max row norm, then the counters: unresolved queries, flagged passes, passes, pad
+  int rc = h->stats.ensure(8 * sizeof(unsigned int));
   if (rc) return rc;
-  if (row0 == 0) AMDR_HIP(hipMemsetAsync(h->stats.p, 0, 4 * sizeof(unsigned int), h->stream));
+  if (row0 == 0) AMDR_HIP(hipMemsetAsync(h->stats.p, 0, 8 * sizeof(unsigned int), h->stream));
   if (!h->hi_host) {
     AMDR_HIP(hipHostMalloc((void**)&h->hi_host, 4 * sizeof(unsigned int), hipHostMallocDefault));
-    h->hi_host[0] = h->hi_host[1] = 0u;
+    h->hi_host[0] = h->hi_host[1] = h->hi_host[2] = 0u;
+    AMDR_HIP(hipEventCreateWithFlags(&h->hi_ev, hipEventDisableTiming));
   }
   if ((rc = dense_stats_launch(h->X + (size_t)row0 * h->d, (long)rows, h->d, h->stats.as<unsigned int>(), h->stream)))
     return rc;
@@ -981,7 +1105,12 @@ int amdr_dense_add(amdr_dense_t* h, const float* X_host, int64_t n_add) {
   h->hi_level = 0;
   h->hi_off = false;
   h->lvl_p0 = h->hi_passes;
-  if (h->hi_host) h->lvl_f0 = ((volatile unsigned int*)h->hi_host)[1];
+  if (h->hi_copy_pending && hipEventSynchronize(h->hi_ev) == hipSuccess) {
+    h->hi_copy_pending = false;
+    for (int i = 0; i < 3; ++i) h->hi_seen[i] = h->hi_host[i];
+  }
+  h->lvl_f0 = h->hi_seen[1];
+  if (hi_tail2()) h->lvl_p0 = (int64_t)h->hi_seen[2];
   return update_stats(h, row0, n_add);
 }
 
@@ -1133,8 +1262,18 @@ int amdr_dense_workspace_plan(int64_t n, int32_t d, int32_t nq, int32_t k, int64
     two_level_need(&h, nq, k, &need);
     out6[0] = (int64_t)need.smat, out6[1] = (int64_t)need.part, out6[2] = (int64_t)need.aux;
     const bool hi = hi_applies(&h, nq, k);
+    if (hi && hi_tail2()) {  // the round-4 tail: passes of up to four query tiles, any of the three widths
+      const int c2 = hi2_chunk(&h, nq);
+      for (int q0 = 0; q0 < nq; q0 += c2)
+        for (int l = 0; l < kHiLevels; ++l) {
+          Hi2Plan p;
+          hi2_plan(&h, nq - q0 < c2 ? nq - q0 : c2, k, hi_kc(k, l), &p);
+          used.smat = p.smat_bytes > used.smat ? p.smat_bytes : used.smat;
+          used.aux = p.aux_bytes + 256 > used.aux ? p.aux_bytes + 256 : used.aux;
+        }
+    }
     const int chunk = hi ? hi_chunk(&h, nq, k) : two_level_chunk(nq, k);
-    for (int q0 = 0; q0 < nq; q0 += chunk) {  // what the pass loop of run_search_two_level touches
+    for (int q0 = 0; q0 < nq; q0 += chunk) {  // what the pass loop of run_search_two_level touches (round-3 tail / given up)
       const int m = nq - q0 < chunk ? nq - q0 : chunk;
       TwoLevelPlan t;
       if (hi)
@@ -1167,6 +1306,19 @@ int amdr_dense_plan_info(const amdr_dense_t* h, int32_t nq, int32_t k, char* buf
   AMDR_REQUIRE(nq >= 1 && k >= 1 && k <= AMDR_MAX_K, "dense_plan_info: bad sizes");
   if (h->n <= 0) {
     snprintf(buf, buf_len, "empty index");
+    return AMDR_OK;
+  }
+  if (hi_applies(h, nq, k) && !h->hi_off && hi_tail2()) {
+    const int m = hi2_chunk(h, nq), kc = hi_kc(k, hi_level_of(h));
+    Hi2Plan p;
+    hi2_plan(h, m, k, kc, &p);
+    snprintf(buf, buf_len,
+             "dense_hi_tilemax_kernel fp16 first pass queries_per_launch=%d (%d per pass, one tail): per-query lists of the "
+             "approximate tile maxima above a sampled threshold (every %ld-th tile, width level %d) -> top-%d + rounding-bound "
+             "check + exact re-scoring of each query's tiles at or above its cut (<= %d each) + top-k: 4 launches behind the "
+             "scan(s), the exact first pass behind a device flag in 2",
+             m < dense_hi_max_queries(h->d) ? m : dense_hi_max_queries(h->d), m,
+             dense_hi2_sample_stride((long)h->n, p.qtiles), hi_level_of(h), kc, kc);
     return AMDR_OK;
   }
   if (hi_applies(h, nq, k) && !h->hi_off) {
@@ -1234,7 +1386,7 @@ int amdr_dense_hi_counters(amdr_dense_t* h, int64_t* out6) {
   out6[0] = h->hi_queries;
   out6[1] = out6[5] = 0;
   if (h->stats.p) {
-    unsigned int c[2] = {0, 0};
+    unsigned int c[3] = {0, 0, 0};
     AMDR_HIP(hipDeviceSynchronize());  // the counters are bumped by kernels on the callers' streams
     AMDR_HIP(hipMemcpy(c, h->stats.as<unsigned int>() + 2, sizeof(c), hipMemcpyDeviceToHost));
     out6[1] = (int64_t)c[0];
@@ -1297,6 +1449,7 @@ int amdr_dense_destroy(amdr_dense_t* h) {
   h->ibuf.release();
   h->stats.release();
   if (h->hi_host) (void)hipHostFree(h->hi_host);
+  if (h->hi_ev) (void)hipEventDestroy(h->hi_ev);
   delete h;
   return AMDR_OK;
 }

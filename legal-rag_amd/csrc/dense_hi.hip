@@ -60,6 +60,13 @@ struct HiEmit {
   unsigned int* total;  // entries appended (may pass cap: the check kernel raises the flag)
   unsigned int cap;
   int wbuf;             // entries of the wave-private staging buffer
+  // per-query lists (round 4; qcount != nullptr): query q's entries (score, tile) go to qlist[q * qcap ..], qcount[q] counts
+  // them (it may pass qcap: dense_hi_select_kernel then raises the flag for that query).  The block bins the staged
+  // entries of its 8 waves by query in LDS and reserves its share of every list with ONE atomic per query (256 blocks x
+  // 64 atomics per scan), instead of one flat list that a second kernel had to filter per query (49 + 11 us).
+  C32* qlist;
+  unsigned int* qcount;
+  unsigned int qcap;
 };
 constexpr int kHiQShift = 26;  // tiles < 2^26
 
@@ -78,27 +85,72 @@ __global__ __launch_bounds__(kHiWaves * 64) void dense_hi_tilemax_kernel(const f
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r32 = lane & 31, h = lane >> 5;
 
-  // ---- the query tile: wave w converts queries 8 w .. 8 w + 7 (scale = 2^-e of the query's largest |component|)
-  for (int qi = wave * 8; qi < wave * 8 + 8 && qi < QT; ++qi) {
-    const bool live = qi < nq;
-    const float* src = Q + (size_t)(live ? qi : 0) * d;
-    float v[D64];
-    float m = 0.f;
+  // grid.y > 1 (the sample of a multi-tile search): block row y works for query tile y
+  if (gridDim.y > 1) {
+    Q += (size_t)blockIdx.y * QT * d;
+    nq -= (int)blockIdx.y * QT;
+    nq = nq < 0 ? 0 : (nq > QT ? QT : nq);
+    MT += (size_t)blockIdx.y * n_items * cols;
+  }
+  // ---- the query tile: wave w converts queries 8 w .. 8 w + 7 (scale = 2^-e of the query's largest |component|).
+  // Lane l owns the 16-byte fp16 chunks l and l + 64 of a query (8 consecutive components each: two 16-byte loads, one
+  // 16-byte LDS store); the loads of FOUR queries are in flight before the first is reduced — one query at a time with
+  // 4-byte loads, shuffles through LDS and 2-byte LDS stores was ~2 us per query, 16 us of every launch of this kernel.
+  {
+    constexpr int CPQ = d / 8, ITS = (CPQ + 63) / 64;
 #pragma unroll
-    for (int j = 0; j < D64; ++j) {
-      v[j] = live ? src[j * 64 + lane] : 0.f;
-      m = fmaxf(m, fabsf(v[j]));
-    }
+    for (int g = 0; g < 2; ++g) {
+      hi4f v[4][ITS][2];
 #pragma unroll
-    for (int sft = 1; sft < 64; sft <<= 1) m = fmaxf(m, __shfl_xor(m, sft));
-    int e = 0;
-    if (m > 0.f && m <= FLT_MAX) (void)frexpf(m, &e);
-    const float sc = ldexpf(1.f, -e);
-    _Float16* row = reinterpret_cast<_Float16*>(qt);
+      for (int j = 0; j < 4; ++j) {
+        const int qi = wave * 8 + g * 4 + j;
+        const bool live = qi < nq;
 #pragma unroll
-    for (int j = 0; j < D64; ++j) {
-      const int k = j * 64 + lane;  // element k of the query: chunk k >> 3, half k & 7
-      row[(hi_q_off(qi, k >> 3, d) >> 1) + (k & 7)] = (_Float16)(v[j] * sc);
+        for (int it = 0; it < ITS; ++it) {
+          const int c = lane + 64 * it;
+          const bool ok = live && c < CPQ;
+          const float* src = Q + (size_t)(ok ? qi : 0) * d + (ok ? c : 0) * 8;
+          const hi4f z = {0.f, 0.f, 0.f, 0.f};
+          v[j][it][0] = ok ? *reinterpret_cast<const hi4f*>(src) : z;
+          v[j][it][1] = ok ? *reinterpret_cast<const hi4f*>(src + 4) : z;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int qi = wave * 8 + g * 4 + j;
+        float m = 0.f;
+#pragma unroll
+        for (int it = 0; it < ITS; ++it)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v[j][it][hh][e]));
+        // (fmaxf drops a NaN operand: a NaN / infinite query is caught by the check on the fp32 query itself)
+        m = fmaxf(m, __uint_as_float(lane_xor<1>(__float_as_uint(m))));
+        m = fmaxf(m, __uint_as_float(lane_xor<2>(__float_as_uint(m))));
+        m = fmaxf(m, __uint_as_float(lane_xor<4>(__float_as_uint(m))));
+        m = fmaxf(m, __uint_as_float(lane_xor<8>(__float_as_uint(m))));
+        m = fmaxf(m, __uint_as_float(lane_xor<16>(__float_as_uint(m))));
+        m = fmaxf(m, __uint_as_float(lane_xor<32>(__float_as_uint(m))));
+        int e = 0;
+        if (m > 0.f && m <= FLT_MAX) (void)frexpf(m, &e);
+        const float sc = ldexpf(1.f, -e);
+        if (qi < QT) {
+#pragma unroll
+          for (int it = 0; it < ITS; ++it) {
+            const int c = lane + 64 * it;
+            if (c < CPQ) {
+              h8 y;
+#pragma unroll
+              for (int e2 = 0; e2 < 4; ++e2) {
+                y[e2] = (_Float16)(v[j][it][0][e2] * sc);
+                y[4 + e2] = (_Float16)(v[j][it][1][e2] * sc);
+              }
+              *reinterpret_cast<h8*>(qt + hi_q_off(qi, c, d)) = y;
+            }
+          }
+        }
+      }
     }
   }
   __syncthreads();
@@ -136,12 +188,24 @@ __global__ __launch_bounds__(kHiWaves * 64) void dense_hi_tilemax_kernel(const f
   C32* wbuf = reinterpret_cast<C32*>(smem + QT * d * 2 + kHiWaves * kHiStageBytes) + (size_t)wave * (EMIT ? em.wbuf : 0);
   int wcnt = 0;
   const float tau = (EMIT && lane < nq) ? em.tau[(size_t)lane * em.tau_stride] : 0.f;
+  const bool perq = EMIT && em.qcount != nullptr;
   auto flush = [&]() {
-    unsigned int base = 0;
-    if (lane == 0) base = atomicAdd(em.total, (unsigned int)wcnt);
-    base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
-    for (int i = lane; i < wcnt; i += 64)
-      if (base + (unsigned int)i < em.cap) em.cand[base + i] = wbuf[i];
+    if (perq) {  // a full buffer in the middle of a run (rare): one returning atomic per entry
+      for (int i = lane; i < wcnt; i += 64) {
+        C32 c = wbuf[i];
+        const unsigned int id = 0xffffffffu - (unsigned int)c.c;
+        const unsigned int q = id >> kHiQShift;
+        c.c = (c.c & 0xffffffff00000000ull) | (u64)(0xffffffffu - (id & ((1u << kHiQShift) - 1u)));
+        const unsigned int pos = atomicAdd(em.qcount + q, 1u);
+        if (pos < em.qcap) em.qlist[(size_t)q * em.qcap + pos] = c;
+      }
+    } else {
+      unsigned int base = 0;
+      if (lane == 0) base = atomicAdd(em.total, (unsigned int)wcnt);
+      base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+      for (int i = lane; i < wcnt; i += 64)
+        if (base + (unsigned int)i < em.cap) em.cand[base + i] = wbuf[i];
+    }
     wcnt = 0;
     wave_lds_fence();
   };
@@ -239,7 +303,43 @@ __global__ __launch_bounds__(kHiWaves * 64) void dense_hi_tilemax_kernel(const f
       }
     }
   }
-  if (EMIT && wcnt > 0) flush();
+  if (EMIT && !perq && wcnt > 0) flush();
+  if (perq) {  // block-uniform: every wave of the block gets here
+    // the staged entries of the block's 8 waves, binned by query: rank inside the block by LDS atomics, one global atomic
+    // per query with an entry reserves the block's share of that query's list
+    int* bh = reinterpret_cast<int*>(smem + QT * d * 2 + kHiWaves * kHiStageBytes + (size_t)kHiWaves * em.wbuf * sizeof(C32));
+    unsigned int* bb = reinterpret_cast<unsigned int*>(bh + 64);
+    if (wave == 0) bh[lane] = 0;
+    __syncthreads();
+    int pos[4];
+    unsigned int qq[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = lane + 64 * j;
+      pos[j] = 0, qq[j] = 0u;
+      if (i < wcnt) {
+        qq[j] = (0xffffffffu - (unsigned int)wbuf[i].c) >> kHiQShift;
+        pos[j] = atomicAdd(bh + qq[j], 1);
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const int c = bh[lane];
+      bb[lane] = c > 0 ? atomicAdd(em.qcount + lane, (unsigned int)c) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = lane + 64 * j;
+      if (i < wcnt) {
+        C32 c = wbuf[i];
+        const unsigned int id = 0xffffffffu - (unsigned int)c.c;
+        c.c = (c.c & 0xffffffff00000000ull) | (u64)(0xffffffffu - (id & ((1u << kHiQShift) - 1u)));
+        const unsigned int dst = bb[qq[j]] + (unsigned int)pos[j];
+        if (dst < em.qcap) em.qlist[(size_t)qq[j] * em.qcap + dst] = c;
+      }
+    }
+  }
 }
 
 // Top-kc of every query from the flat list of the emitting scan, step 1: block (part p, query q) reads the p-th slice of
@@ -406,25 +506,26 @@ static int hi_wbuf_entries(int d) {  // 16 / 8 KiB of LDS for the 8 waves
   return d <= 768 ? 256 : 128;
 }
 static size_t dense_hi_lds(int d, bool emit) {
-  return (size_t)hi_query_tile(d) * d * 2 + kHiWaves * kHiStageBytes + (emit ? (size_t)kHiWaves * hi_wbuf_entries(d) * sizeof(C32) : 0);
+  return (size_t)hi_query_tile(d) * d * 2 + kHiWaves * kHiStageBytes +
+         (emit ? (size_t)kHiWaves * hi_wbuf_entries(d) * sizeof(C32) + 128 * sizeof(int) : 0);
 }
 
 template <int D64, bool EMIT>
 static int launch_hi(const float* X, long n, const float* Q, int nq, int grid, float* MT, float x_scale, long tile_stride,
-                     long n_items, const HiEmit& em, hipStream_t st) {
+                     long n_items, const HiEmit& em, hipStream_t st, int grid_y = 1) {
   const size_t lds = dense_hi_lds(D64 * 64, EMIT);
   AMDR_HIP(hipFuncSetAttribute((const void*)dense_hi_tilemax_kernel<D64, EMIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds));
-  hipLaunchKernelGGL((dense_hi_tilemax_kernel<D64, EMIT>), dim3(grid), dim3(kHiWaves * 64), lds, st, X, n, Q, nq, MT,
-                     hi_mt_cols(nq), x_scale, tile_stride, n_items, em);
+  hipLaunchKernelGGL((dense_hi_tilemax_kernel<D64, EMIT>), dim3(grid, grid_y), dim3(kHiWaves * 64), lds, st, X, n, Q, nq, MT,
+                     grid_y > 1 ? 64 : hi_mt_cols(nq), x_scale, tile_stride, n_items, em);
   AMDR_HIP(hipGetLastError());
   return AMDR_OK;
 }
 
 template <bool EMIT>
 static int launch_hi_d(const float* X, long n, int d, const float* Q, int nq, float* MT, float x_scale, long tile_stride,
-                       const HiEmit& em, hipStream_t st) {
-  if (!dense_hi_supported(d) || nq < 1 || nq > hi_query_tile(d)) return fail(AMDR_EINVAL, "dense (fp16 first pass): d=%d nq=%d", d, nq);
+                       const HiEmit& em, hipStream_t st, int grid_y = 1) {
+  if (!dense_hi_supported(d) || nq < 1 || nq > grid_y * hi_query_tile(d)) return fail(AMDR_EINVAL, "dense (fp16 first pass): d=%d nq=%d", d, nq);
   // one persistent block per CU (the query tile fills most of its LDS)
   int dev = 0, cus = 256;
   AMDR_HIP(hipGetDevice(&dev));
@@ -436,14 +537,14 @@ static int launch_hi_d(const float* X, long n, int d, const float* Q, int nq, fl
   if (blocks < 1) blocks = 1;
   const int grid = (int)blocks;
   switch (d / 64) {
-    case 2: return launch_hi<2, EMIT>(X, n, Q, nq, grid, MT, x_scale, tile_stride, n_items, em, st);
-    case 4: return launch_hi<4, EMIT>(X, n, Q, nq, grid, MT, x_scale, tile_stride, n_items, em, st);
-    case 6: return launch_hi<6, EMIT>(X, n, Q, nq, grid, MT, x_scale, tile_stride, n_items, em, st);
-    case 8: return launch_hi<8, EMIT>(X, n, Q, nq, grid, MT, x_scale, tile_stride, n_items, em, st);
-    case 10: return launch_hi<10, EMIT>(X, n, Q, nq, grid, MT, x_scale, tile_stride, n_items, em, st);
-    case 12: return launch_hi<12, EMIT>(X, n, Q, nq, grid, MT, x_scale, tile_stride, n_items, em, st);
-    case 14: return launch_hi<14, EMIT>(X, n, Q, nq, grid, MT, x_scale, tile_stride, n_items, em, st);
-    case 16: return launch_hi<16, EMIT>(X, n, Q, nq, grid, MT, x_scale, tile_stride, n_items, em, st);
+    case 2: return launch_hi<2, EMIT>(X, n, Q, nq, grid, MT, x_scale, tile_stride, n_items, em, st, grid_y);
+    case 4: return launch_hi<4, EMIT>(X, n, Q, nq, grid, MT, x_scale, tile_stride, n_items, em, st, grid_y);
+    case 6: return launch_hi<6, EMIT>(X, n, Q, nq, grid, MT, x_scale, tile_stride, n_items, em, st, grid_y);
+    case 8: return launch_hi<8, EMIT>(X, n, Q, nq, grid, MT, x_scale, tile_stride, n_items, em, st, grid_y);
+    case 10: return launch_hi<10, EMIT>(X, n, Q, nq, grid, MT, x_scale, tile_stride, n_items, em, st, grid_y);
+    case 12: return launch_hi<12, EMIT>(X, n, Q, nq, grid, MT, x_scale, tile_stride, n_items, em, st, grid_y);
+    case 14: return launch_hi<14, EMIT>(X, n, Q, nq, grid, MT, x_scale, tile_stride, n_items, em, st, grid_y);
+    case 16: return launch_hi<16, EMIT>(X, n, Q, nq, grid, MT, x_scale, tile_stride, n_items, em, st, grid_y);
     default: return fail(AMDR_EINVAL, "dense (fp16 first pass): unsupported dim %d", d);
   }
 }
@@ -520,6 +621,260 @@ int dense_stats_launch(const float* X, long n, int d, unsigned int* out2, hipStr
   long blocks = (n + 3) / 4;  // a wave per row and round
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(dense_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, st, X, n, d, out2);
+  AMDR_HIP(hipGetLastError());
+  return AMDR_OK;
+}
+
+
+// =====================================================================================================================
+// Round 4: the tail of a large search behind the scan in FOUR launches (+ two gated ones) instead of ~eighteen.
+//   sample (all query tiles of the search in one launch) -> dense_hi_tau_kernel -> scan(s), per-query lists
+//   -> dense_hi_select_kernel (top-kc of a query's list + the rounding-bound check + its tiles at or above the cut,
+//      ascending) -> [gated on the flag: exact tile maxima of the batch, dense_hi_exact_select_kernel for the queries the
+//      bound did not resolve] -> dense_rescore_tiles_kernel + final top-k with the column -> row map (dense_mfma.hip).
+// At 8 GPUs a rank scans 1.25 M rows in 0.6 ms: the 0.22-0.25 ms of small kernels behind the scan was what capped the
+// 1 -> 8 curve.
+// =====================================================================================================================
+
+// tau[q] = the kc-th largest sampled tile maximum of query q (a lower bound of the kc-th largest over ALL tiles), NaN
+// when the sample holds fewer than kc real maxima.  One wave per query, the <= 2 048 sampled maxima in registers, the
+// kc-th largest found bit by bit on the ordered keys (32 x (compare-count + wave sum)); no sort, no transposition pass.
+// Also the per-search reset: the query's list counter, and (block 0) the flag and the pass counter.
+__global__ __launch_bounds__(64) void dense_hi_tau_kernel(const float* __restrict__ MT, int items, int cols, int qt, int kc,
+                                                          float* __restrict__ tau, unsigned int* __restrict__ qcount,
+                                                          int* __restrict__ flag, unsigned int* __restrict__ stats,
+                                                          int qtiles) {
+  const int q = blockIdx.x, lane = threadIdx.x;
+  const int y = q / qt, c = q - y * qt;
+  const float* col = MT + (size_t)y * items * cols + c;
+  u32 key[32];
+#pragma unroll
+  for (int v = 0; v < 32; ++v) {
+    const int i = lane + 64 * v;
+    key[v] = i < items ? ord32(col[(size_t)i * cols]) : 0u;
+  }
+  u32 K = 0u;
+#pragma unroll 1
+  for (int bit = 31; bit >= 0; --bit) {
+    const u32 cand = K | (1u << bit);
+    int cnt = 0;
+#pragma unroll
+    for (int v = 0; v < 32; ++v) cnt += key[v] >= cand ? 1 : 0;
+    cnt = wave_allsum_i32(cnt);
+    if (cnt >= kc) K = cand;
+  }
+  if (lane == 0) {
+    tau[q] = K > 1u ? unord32(K) : __uint_as_float(0x7fc00000u);  // key 1 = a NaN maximum, 0 = nothing
+    qcount[q] = 0u;
+    if (q == 0) {
+      *flag = 0;
+      // passes through the fp16 first pass, in query tiles (the unit the width adaptation was tuned on), counted where
+      // the flags are counted (a hipGraph replay bumps both)
+      atomicAdd(stats + 4, (unsigned int)qtiles);
+    }
+  }
+}
+
+// One block per query: (1) the kc best entries of the query's candidate list (score desc, tile asc — the order of every
+// top-k here); (2) the check of dense_hi_check_kernel: is every tile that can hold one of the k best rows among them?
+// (3) resolved -> the tiles at or above the cut T_k - 2 eps, ASCENDING, into list[q * kc ..], count[q]; unresolved ->
+// count[q] = 0, unres[q] = 1, the flag raised: the gated exact pass fills the query's list instead.
+__global__ __launch_bounds__(256) void dense_hi_select_kernel(const C32* __restrict__ qlist,
+                                                              const unsigned int* __restrict__ qcount, unsigned int qcap,
+                                                              int kc1, int k, int tcap, const float* __restrict__ Q, int d,
+                                                              float row_norm_max, float x_scale, int x_exp, long n_tiles,
+                                                              int* __restrict__ list, int* __restrict__ count,
+                                                              int* __restrict__ unres, int* __restrict__ flag,
+                                                              unsigned int* __restrict__ unresolved, int qtiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  C32* lists = reinterpret_cast<C32*>(smem);
+  int* cnts = reinterpret_cast<int*>(lists + (size_t)4 * tcap);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = blockIdx.x;
+  const unsigned int have = qcount[q];
+  const unsigned int n = have < qcap ? have : qcap;
+  const C32* src = qlist + (size_t)q * qcap;
+  WaveTopK<C32> tk;
+  tk.init(lists + (size_t)wave * tcap, tcap, kc1);
+  constexpr int UN = 4;  // entries per lane requested before the first is looked at
+  for (unsigned int base = (unsigned int)wave * 64; base < n; base += 256 * UN) {
+    C32 e[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const unsigned int i = base + 256 * u + lane;
+      e[u] = i < n ? src[i] : C32::pad();
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) tk.push_lanes(e[u], !e[u].is_pad(), lane);
+  }
+  tk.finalize(lane);
+  block_combine_topk(tk, lists, tcap, 4, wave, lane, cnts);
+  if (wave != 0) return;
+  // ---- the rounding bound of this query (dense_hi_check_kernel states it)
+  float amax = 0.f;
+  bool nan = false;
+  for (int j = lane; j < d; j += 64) {
+    const float x = Q[(size_t)q * d + j];
+    nan |= x != x;
+    amax = fmaxf(amax, fabsf(x));
+  }
+#pragma unroll
+  for (int sft = 1; sft < 64; sft <<= 1) amax = fmaxf(amax, __uint_as_float(lane_xor_sw(__float_as_uint(amax), sft)));
+  nan = __any(nan);
+  int e = 0;
+  if (amax > 0.f && amax <= FLT_MAX) (void)frexpf(amax, &e);
+  const float sc = ldexpf(1.f, -e);
+  float ss = 0.f;
+  for (int j = lane; j < d; j += 64) {
+    const float x = Q[(size_t)q * d + j] * sc;
+    ss += x * x;
+  }
+#pragma unroll
+  for (int sft = 1; sft < 64; sft <<= 1) ss += __uint_as_float(lane_xor_sw(__float_as_uint(ss), sft));
+  const float rel = 1.125f * (9.765625e-4f + 2.4e-7f + 2.f * (float)(d + 8) * 5.9604645e-8f);
+  const float eps = rel * sqrtf(ss) * (row_norm_max * x_scale) + 1.125f * (float)d * 5.9604645e-8f;
+  const bool bad = nan || !(amax <= FLT_MAX) || !(eps == eps) || e + x_exp > 100 || e + x_exp < -100;
+  const int cnt = tk.cnt;
+  const long want = n_tiles < kc1 ? n_tiles : (long)kc1;
+  bool raise = bad || have > qcap || cnt < want;  // an overflowed list or too few candidates (NaN threshold): the exact chain decides
+  float cut = -FLT_MAX;
+  if (!raise && n_tiles >= kc1) {  // fewer tiles than candidates: every tile is one already
+    const float Tk = tk.buf[k - 1].score(), last = tk.buf[kc1 - 1].score();
+    cut = Tk - 2.f * eps;
+    raise = !(last < cut);
+  }
+  if (raise) {
+    if (lane == 0) {
+      count[q] = 0;
+      unres[q] = 1;
+      if (atomicOr(flag, 1) == 0) atomicAdd(unresolved + 1, (unsigned int)qtiles);  // passes (query tiles) whose flag went up
+      atomicAdd(unresolved, 1u);                                                     // queries
+    }
+    return;
+  }
+  // the tiles at or above the cut (the list is sorted by maximum: a prefix), ascending by tile: rank = smaller tiles
+  int keep = 0;
+  for (int j0 = 0; j0 < cnt; j0 += 64) {
+    const int j = j0 + lane;
+    keep += __popcll(__ballot(j < cnt && !(tk.buf[j].score() < cut)));
+  }
+  for (int j = lane; j < keep; j += 64) {
+    const long long t = tk.buf[j].id();
+    int rank = 0;
+    for (int i = 0; i < keep; ++i) rank += tk.buf[i].id() < t ? 1 : 0;
+    list[(size_t)q * kc1 + rank] = (int)t;
+  }
+  if (lane == 0) {
+    count[q] = keep;
+    unres[q] = 0;
+  }
+}
+
+// Gated (the flag of the pass) and per query (unres[q]): the k tiles with the largest EXACT maxima M[q][tile] (fp32 matrix
+// instructions, dense_mfma.hip mode 1) — step 2 of the exact two-level form — ascending into the query's list.  The exact
+// re-scoring and the final top-k then treat every query of the batch alike.
+__global__ __launch_bounds__(256) void dense_hi_exact_select_kernel(const float* __restrict__ M, long ldM, long n_tiles, int k,
+                                                                    int tcap, int list_stride, int* __restrict__ list,
+                                                                    int* __restrict__ count, const int* __restrict__ unres,
+                                                                    const int* __restrict__ gate) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (*gate == 0) return;
+  const int q = blockIdx.x;
+  if (unres[q] == 0) return;
+  C32* lists = reinterpret_cast<C32*>(smem);
+  int* cnts = reinterpret_cast<int*>(lists + (size_t)4 * tcap);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* row = M + (size_t)q * ldM;
+  WaveTopK<C32> tk;
+  tk.init(lists + (size_t)wave * tcap, tcap, k);
+  for (long base = (long)wave * 256; base < n_tiles; base += 4 * 256) {  // ldM is a multiple of 32 floats: whole float4s
+    const long r0 = base + 4 * lane;
+    const hi4f z = {0.f, 0.f, 0.f, 0.f};
+    const hi4f x = r0 < n_tiles ? *reinterpret_cast<const hi4f*>(row + r0) : z;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long r = r0 + e;
+      const bool v = r < n_tiles;
+      tk.push_lanes(v ? C32::make(x[e], (u32)r) : C32::pad(), v, lane);
+    }
+  }
+  tk.finalize(lane);
+  block_combine_topk(tk, lists, tcap, 4, wave, lane, cnts);
+  if (wave != 0) return;
+  const int keep = tk.cnt;
+  for (int j = lane; j < keep; j += 64) {
+    const long long t = tk.buf[j].id();
+    int rank = 0;
+    for (int i = 0; i < keep; ++i) rank += tk.buf[i].id() < t ? 1 : 0;
+    list[(size_t)q * list_stride + rank] = (int)t;
+  }
+  if (lane == 0) count[q] = keep;
+}
+
+// ---- host side of the round-4 tail -------------------------------------------------------------------------------------
+// the sample of a search with `qtiles` query tiles: 2 048 / qtiles items per tile (one item per wave of the grid, all
+// tiles in ONE launch)
+long dense_hi2_sample_stride(long n, int qtiles) {
+  const long tiles = (n + 31) / 32;
+  long per = 2048 / (qtiles < 1 ? 1 : qtiles);
+  per = per / kHiWaves * kHiWaves;
+  if (per < kHiWaves) per = kHiWaves;
+  const long s = (tiles + per - 1) / per;
+  return s < 1 ? 1 : s;
+}
+long dense_hi2_sample_items(long n, int qtiles) {
+  const long tiles = (n + 31) / 32, s = dense_hi2_sample_stride(n, qtiles);
+  return (tiles + s - 1) / s;
+}
+// entries of ONE query's candidate list: 4x the expected kc * stride, at least 1 024; never more than every tile
+size_t dense_hi2_qcap(long n, int qtiles, int kc) {
+  size_t e = (size_t)kc * dense_hi2_sample_stride(n, qtiles) * 4 + 1024;
+  const char* env = getenv("AMDR_DENSE_HI_CAP");  // test hook (entries per 64 queries): short lists overflow -> the exact chain takes over
+  if (env && atol(env) >= 64) e = (size_t)atol(env) / 64;
+  const size_t all = (size_t)((n + 31) / 32);
+  return e < all ? e : all;
+}
+int dense_hi2_launch_sample(const float* X, long n, int d, const float* Q, int nq, int qtiles, float* MT, hipStream_t st,
+                            float x_scale) {
+  HiEmit em{};
+  return launch_hi_d<false>(X, n, d, Q, nq, MT, x_scale, dense_hi2_sample_stride(n, qtiles), em, st, qtiles);
+}
+int dense_hi2_launch_tau(const float* MT, long n, int d, int nq, int qtiles, int kc, float* tau, unsigned int* qcount,
+                         int* flag, unsigned int* stats, hipStream_t st) {
+  const int items = (int)dense_hi2_sample_items(n, qtiles);
+  if (items > 2048) return fail(AMDR_EINVAL, "dense (fp16 first pass): %d sample items", items);
+  hipLaunchKernelGGL(dense_hi_tau_kernel, dim3(nq), dim3(64), 0, st, MT, items, qtiles > 1 ? 64 : hi_mt_cols(nq),
+                     hi_query_tile(d), kc, tau, qcount, flag, stats, qtiles);
+  AMDR_HIP(hipGetLastError());
+  return AMDR_OK;
+}
+// the scan of ONE query tile: maxima >= tau[q] into the per-query lists
+int dense_hi2_launch_emit(const float* X, long n, int d, const float* Q, int nq, const float* tau, void* qlist,
+                          unsigned int* qcount, size_t qcap, hipStream_t st, float x_scale) {
+  if ((n + 31) / 32 >= (1l << kHiQShift)) return fail(AMDR_EINVAL, "dense (fp16 first pass): too many tiles");
+  HiEmit em{tau, 1, nullptr, nullptr, 0u, hi_wbuf_entries(d), (C32*)qlist, qcount, (unsigned int)qcap};
+  return launch_hi_d<true>(X, n, d, Q, nq, nullptr, x_scale, 1, em, st);
+}
+int dense_hi2_launch_select(const void* qlist, const unsigned int* qcount, size_t qcap, int m, int kc, int k, const float* Q,
+                            int d, float row_norm_max, float x_scale, long n_tiles, int* list, int* count, int* unres,
+                            int* flag, unsigned int* unresolved, hipStream_t st) {
+  int x_exp = 0;
+  (void)frexpf(x_scale, &x_exp);  // x_scale = 2^-ex = 0.5 * 2^(1 - ex)
+  x_exp = 1 - x_exp;
+  const int tcap = topk_cap(kc);
+  const size_t lds = (size_t)4 * tcap * sizeof(C32) + 4 * sizeof(int);
+  hipLaunchKernelGGL(dense_hi_select_kernel, dim3(m), dim3(256), lds, st, (const C32*)qlist, qcount, (unsigned int)qcap, kc, k,
+                     tcap, Q, d, row_norm_max, x_scale, x_exp, n_tiles, list, count, unres, flag, unresolved,
+                     (m + hi_query_tile(d) - 1) / hi_query_tile(d));
+  AMDR_HIP(hipGetLastError());
+  return AMDR_OK;
+}
+int dense_hi2_launch_exact_select(const float* M, long ldM, long n_tiles, int m, int k, int list_stride, int* list, int* count,
+                                  const int* unres, const int* gate, hipStream_t st) {
+  const int tcap = topk_cap(k);
+  const size_t lds = (size_t)4 * tcap * sizeof(C32) + 4 * sizeof(int);
+  hipLaunchKernelGGL(dense_hi_exact_select_kernel, dim3(m), dim3(256), lds, st, M, ldM, n_tiles, k, tcap, list_stride, list,
+                     count, unres, gate);
   AMDR_HIP(hipGetLastError());
   return AMDR_OK;
 }

@@ -628,6 +628,169 @@ int dense_tiles_remap_launch(int64_t* ids, int total, const int* list, const int
   return AMDR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4: exact scores of every query's OWN candidate tiles behind the fp16 first pass, lean form.  Mode 3 of the tile
+// kernel above did this with a whole 32-query LDS tile per block (96 KiB staged, 31 of 32 MFMA columns idle, one block
+// per CU: 38 us per 64 queries).  Here a wave scores ONE (query, tile): the tile's rows stream through the wave's 4-KiB
+// stage exactly as above (same loads, same fragments), the B operand is the query's own components broadcast to all 16
+// columns, and only the two row blocks are multiplied: 16 MFMAs per chunk instead of 32, the k-steps in the SAME order —
+// acc[bj] sees the sequence the tile kernel's acc[bi][bj] sees, hence the same bits (tested against modes 0 / 2 / 3).
+// 20 KiB of LDS per 4-wave block: the candidate tiles of a batch spread over every CU.
+// grid: (ceil(max tiles per query / WPB), queries).
+template <int D8, int WPB>
+__global__ __launch_bounds__(WPB * 64) void dense_rescore_tiles_kernel(const float* __restrict__ X, long n_real,
+                                                                       const float* __restrict__ Q,
+                                                                       const int* __restrict__ list,
+                                                                       const int* __restrict__ count, int list_stride,
+                                                                       long ldS, float* __restrict__ S) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int d = D8 * 8;
+  constexpr int NCH = d / kKC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = blockIdx.y;
+  const int cnt = count[q];
+  if ((int)blockIdx.x * WPB >= cnt) return;  // block-uniform: nothing of this query's list falls to the block
+  v4f* qv = reinterpret_cast<v4f*>(smem);
+  for (int i = threadIdx.x; i < d / 4; i += WPB * 64) qv[i] = *reinterpret_cast<const v4f*>(Q + (size_t)q * d + 4 * i);
+  __syncthreads();
+  const int t = blockIdx.x * WPB + wave;
+  if (t >= cnt) return;
+  unsigned char* stage = smem + (size_t)d * 4 + (size_t)wave * kStageBytes;
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int lrow = lane >> 3, lslot = lane & 7;
+  int xoff[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) xoff[u] = stage_off(i16, 4 * u + kq);
+  const long src0 = (long)list[(size_t)q * list_stride + t] * 32;
+  const float* gp[kPieces];
+#pragma unroll
+  for (int p = 0; p < kPieces; ++p) {
+    long r = src0 + 8 * p + lrow;
+    if (r >= n_real) r = n_real - 1;
+    gp[p] = X + (size_t)r * d + lslot * 4;
+  }
+  v4f G[kDepth][kPieces], FX[2][2][2], FQ[2][2];
+#pragma unroll
+  for (int j = 0; j < kDepth; ++j) {
+    if (j < NCH) {
+#pragma unroll
+      for (int p = 0; p < kPieces; ++p) G[j][p] = *reinterpret_cast<const v4f*>(gp[p] + j * kKC);
+    }
+  }
+#define AMDR_RS_FRAGS(ST, C, FX_, FQ_)                                                     \
+  _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_) {                                       \
+    FX_[0][u_] = *reinterpret_cast<const v4f*>((ST) + xoff[u_]);                           \
+    FX_[1][u_] = *reinterpret_cast<const v4f*>((ST) + 2048 + xoff[u_]);                    \
+    FQ_[u_] = qv[8 * (C) + 4 * u_ + kq];                                                   \
+  }
+#define AMDR_RS_KSTEP(FX_, FQ_, U, COMP)                                                              \
+  acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(FX_[0][U].COMP, FQ_[U].COMP, acc[0], 0, 0, 0);        \
+  acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(FX_[1][U].COMP, FQ_[U].COMP, acc[1], 0, 0, 0);
+  AMDR_STAGE_CHUNK(stage, G[0])
+  if (kDepth < NCH) {
+#pragma unroll
+    for (int p = 0; p < kPieces; ++p) G[0][p] = *reinterpret_cast<const v4f*>(gp[p] + kDepth * kKC);
+  }
+  wave_lds_fence();
+  AMDR_RS_FRAGS(stage, 0, FX[0], FQ[0])
+  f32x4 acc[2];  // acc[bj][r] = <row 16 bj + 4 kq + r of the tile, the query>, the same in every column i16
+  acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+  acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    if (c + 1 < NCH) {
+      AMDR_STAGE_CHUNK(stage, G[(c + 1) % kDepth])
+      if (c + 1 + kDepth < NCH) {
+#pragma unroll
+        for (int p = 0; p < kPieces; ++p) G[(c + 1) % kDepth][p] = *reinterpret_cast<const v4f*>(gp[p] + (c + 1 + kDepth) * kKC);
+      }
+      AMDR_RS_FRAGS(stage, c + 1, FX[(c + 1) & 1], FQ[(c + 1) & 1])
+    }
+    AMDR_RS_KSTEP(FX[c & 1], FQ[c & 1], 0, x) AMDR_RS_KSTEP(FX[c & 1], FQ[c & 1], 0, y)
+    AMDR_RS_KSTEP(FX[c & 1], FQ[c & 1], 0, z) AMDR_RS_KSTEP(FX[c & 1], FQ[c & 1], 0, w)
+    AMDR_RS_KSTEP(FX[c & 1], FQ[c & 1], 1, x) AMDR_RS_KSTEP(FX[c & 1], FQ[c & 1], 1, y)
+    AMDR_RS_KSTEP(FX[c & 1], FQ[c & 1], 1, z) AMDR_RS_KSTEP(FX[c & 1], FQ[c & 1], 1, w)
+    wave_lds_fence();
+  }
+#undef AMDR_RS_FRAGS
+#undef AMDR_RS_KSTEP
+  if (i16 == 0) {
+    float* srow = S + (size_t)q * ldS + (size_t)t * 32 + 4 * kq;
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj) {
+      f32x4 v = acc[bj];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (src0 + 16 * bj + 4 * kq + r >= n_real) v[r] = -FLT_MAX;  // rows past the end inside the last tile
+      *reinterpret_cast<f32x4*>(srow + 16 * bj) = v;
+    }
+  }
+}
+
+// The final top-k of every query over the re-scored columns of ITS tiles (32 per list entry, count[q] entries), with the
+// column -> row id map in the epilogue (columns ascend with the rows: ties already went to the lower id).  A column
+// past the end of the matrix (score -FLT_MAX) can only surface when fewer than k rows are real: id -1.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void dense_final_topk_kernel(const float* __restrict__ S, long ldS,
+                                                                      const int* __restrict__ list,
+                                                                      const int* __restrict__ count, int list_stride,
+                                                                      long n_real, int k, int cap,
+                                                                      float* __restrict__ fin_scores,
+                                                                      long long* __restrict__ fin_ids) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  C32* lists = reinterpret_cast<C32*>(smem);
+  int* cnts = reinterpret_cast<int*>(lists + (size_t)WAVES * cap);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int qi = blockIdx.x;
+  const long hi = (long)count[qi] * 32;
+  const float* row = S + (size_t)qi * ldS;
+  WaveTopK<C32> tk;
+  tk.init(lists + (size_t)wave * cap, cap, k);
+  bool done = false;
+  if (WAVES == 1 && k <= 64 && hi <= kSelectRowsMax) {
+    int got;
+    if (hi <= 512)
+      got = select_row<8>(row, 0, hi, k, lane, tk.buf);
+    else if (hi <= 1024)
+      got = select_row<16>(row, 0, hi, k, lane, tk.buf);
+    else
+      got = select_row<32>(row, 0, hi, k, lane, tk.buf);
+    if (got >= 0) {
+      tk.cnt = got;
+      done = true;
+    }
+  }
+  if (!done) {
+    for (long base = (long)wave * 256; base < hi; base += (long)WAVES * 256) {
+      const long r0 = base + 4 * lane;
+      const v4f z = {0.f, 0.f, 0.f, 0.f};
+      const v4f x = (r0 < hi) ? *reinterpret_cast<const v4f*>(row + r0) : z;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const long r = r0 + e;
+        const bool v = r < hi;
+        tk.push_lanes(v ? C32::make(x[e], (u32)r) : C32::pad(), v, lane);
+      }
+    }
+    tk.finalize(lane);
+  }
+  if (WAVES > 1) block_combine_topk(tk, lists, cap, WAVES, wave, lane, cnts);
+  if (wave == 0) {
+    for (int j = lane; j < k; j += 64) {
+      const bool v = j < tk.cnt;
+      const C32 c = v ? tk.buf[j] : C32::pad();
+      long long id = -1ll;
+      if (v) {
+        const long long col = c.id();
+        const long long r = (long long)list[(size_t)qi * list_stride + (col >> 5)] * 32 + (col & 31);
+        id = r < n_real ? r : -1ll;
+      }
+      fin_scores[(size_t)qi * k + j] = v ? c.score() : -FLT_MAX;
+      fin_ids[(size_t)qi * k + j] = id;
+    }
+  }
+}
+
 bool dense_mfma_supported(int d) { return d >= 64 && d <= 1024 && d % 64 == 0; }
 
 // Plan shared by reserve and launch.
@@ -743,6 +906,50 @@ int dense_mfma_launch_topk(const DenseMfmaPlan& p, const float* S, long n, int n
   else
     hipLaunchKernelGGL(scores_slab_topk_kernel<kBW>, dim3(p.slabs, nq), dim3(256), lds, st, S, p.ld, n, nq, k, p.cap,
                        p.rows_per_slab, (C32*)part, fin_scores, (long long*)fin_ids, gate);
+  AMDR_HIP(hipGetLastError());
+  return AMDR_OK;
+}
+
+
+template <int D8>
+static int launch_rescore(const float* X, long n_real, const float* Q, int m, const int* list, const int* count,
+                          int list_stride, int max_tiles, long ldS, float* S, hipStream_t st) {
+  constexpr int WPB = 4;
+  const size_t lds = (size_t)D8 * 8 * sizeof(float) + (size_t)WPB * kStageBytes;
+  hipLaunchKernelGGL((dense_rescore_tiles_kernel<D8, WPB>), dim3((max_tiles + WPB - 1) / WPB, m), dim3(WPB * 64), lds, st, X,
+                     n_real, Q, list, count, list_stride, ldS, S);
+  return AMDR_OK;
+}
+// S[q][32 t ..] = exact scores of the rows of tile list[q * list_stride + t], t < count[q] (<= max_tiles)
+int dense_rescore_tiles_launch(const float* X, long n_real, int d, const float* Q, int m, const int* list, const int* count,
+                               int list_stride, int max_tiles, long ldS, float* S, hipStream_t st) {
+  int rc = AMDR_OK;
+  switch (d) {
+#define AMDR_CASE(D) \
+  case D: rc = launch_rescore<D / 8>(X, n_real, Q, m, list, count, list_stride, max_tiles, ldS, S, st); break;
+    AMDR_CASE(64) AMDR_CASE(128) AMDR_CASE(192) AMDR_CASE(256) AMDR_CASE(320) AMDR_CASE(384)
+    AMDR_CASE(448) AMDR_CASE(512) AMDR_CASE(576) AMDR_CASE(640) AMDR_CASE(704) AMDR_CASE(768)
+    AMDR_CASE(832) AMDR_CASE(896) AMDR_CASE(960) AMDR_CASE(1024)
+#undef AMDR_CASE
+    default: return fail(AMDR_EINVAL, "dense (re-scoring): unsupported dim %d", d);
+  }
+  if (rc) return rc;
+  AMDR_HIP(hipGetLastError());
+  return AMDR_OK;
+}
+// final (scores, row ids) of every query from S (dense_rescore_tiles_launch's layout)
+int dense_final_topk_launch(const float* S, long ldS, const int* list, const int* count, int list_stride, int max_tiles,
+                            long n_real, int m, int k, float* fin_scores, int64_t* fin_ids, hipStream_t st) {
+  const int cap = topk_cap(k);
+  const bool one = (long)max_tiles * 32 <= kSelectRowsMax && k <= 64;
+  const int waves = one ? 1 : kBW;
+  const size_t lds = (size_t)waves * cap * sizeof(C32) + waves * sizeof(int);
+  if (one)
+    hipLaunchKernelGGL(dense_final_topk_kernel<1>, dim3(m), dim3(64), lds, st, S, ldS, list, count, list_stride, n_real, k, cap,
+                       fin_scores, (long long*)fin_ids);
+  else
+    hipLaunchKernelGGL(dense_final_topk_kernel<kBW>, dim3(m), dim3(kBW * 64), lds, st, S, ldS, list, count, list_stride, n_real,
+                       k, cap, fin_scores, (long long*)fin_ids);
   AMDR_HIP(hipGetLastError());
   return AMDR_OK;
 }

@@ -28,6 +28,10 @@ struct ShardLayout {
   int n, row;                           // channels, int64 words per query row
 };
 
+// element `c` of a 4-entry kernel-argument array by a compare chain: a dynamic index would copy the whole argument struct
+// to scratch memory in every thread (measured: the k = 10 merge of 7 128 waves took 40 us with it)
+#define SHARD_PICK(ARR, c) ((c) == 0 ? (ARR)[0] : (c) == 1 ? (ARR)[1] : (c) == 2 ? (ARR)[2] : (ARR)[3])
+
 __global__ __launch_bounds__(256) void shard_pack_kernel(ShardLayout L, int nq, long long offset,
                                                          long long* __restrict__ send) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -37,14 +41,16 @@ __global__ __launch_bounds__(256) void shard_pack_kernel(ShardLayout L, int nq, 
 #pragma unroll
   for (int c = 1; c < kShardChans; ++c)
     if (c < L.n && j >= L.col[c]) ch = c;
-  const int k = L.k[ch], jj = j - L.col[ch];
+  const int k = SHARD_PICK(L.k, ch), jj = j - SHARD_PICK(L.col, ch);
+  const void* sp = SHARD_PICK(L.scores, ch);
+  const long long* ip = SHARD_PICK(L.ids, ch);
   long long w;
   if (jj < k) {
-    const double s = L.f64[ch] ? reinterpret_cast<const double*>(L.scores[ch])[(size_t)q * k + jj]
-                               : (double)reinterpret_cast<const float*>(L.scores[ch])[(size_t)q * k + jj];
+    const double s = SHARD_PICK(L.f64, ch) ? reinterpret_cast<const double*>(sp)[(size_t)q * k + jj]
+                                           : (double)reinterpret_cast<const float*>(sp)[(size_t)q * k + jj];
     w = __double_as_longlong(s);
   } else {
-    const long long id = L.ids[ch][(size_t)q * k + (jj - k)];
+    const long long id = ip[(size_t)q * k + (jj - k)];
     w = id >= 0 ? id + offset : id;
   }
   send[idx] = w;
@@ -60,15 +66,29 @@ __device__ __forceinline__ C64 shard_cand(const long long* __restrict__ g, int n
   return C64::make(__longlong_as_double(r[j]), id);
 }
 
-// sorted (descending) 64-lane sequence from a bitonic one: the merge half of the network
-__device__ __forceinline__ C64 wave_bitonic_merge64_desc(C64 v, int lane) {
+// Bitonic network across the 64 lanes on (key, id) pairs kept as two separate registers pairs: selecting a 16-byte
+// struct with `cond ? v : o` (topk.hpp wave_sortN_desc<C64>) made hipcc park both in scratch memory and load one back
+// through a computed address — 40 B of scratch per lane and a memory round trip per stage.
+__device__ __forceinline__ void cx64(u64& key, long long& idv, int stride, bool keep_better) {
+  const u64 ok = lane_xor_sw(key, stride);
+  const long long oi = (long long)lane_xor_sw((u64)idv, stride);
+  const bool mine_better = key > ok || (key == ok && idv < oi);
+  const bool keep = keep_better == mine_better;
+  key = keep ? key : ok;
+  idv = keep ? idv : oi;
+}
+__device__ __forceinline__ void shard_sort64_desc(u64& key, long long& idv, int lane) {
 #pragma unroll
-  for (int stride = 32; stride > 0; stride >>= 1) {
-    const C64 o = wave_xchg_xor(v, stride);
-    const bool keep_better = (lane & stride) == 0;
-    v = (keep_better == better(v, o)) ? v : o;
+  for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+    for (int stride = size >> 1; stride > 0; stride >>= 1)
+      cx64(key, idv, stride, ((size == 64) || (lane & size) == 0) == ((lane & stride) == 0));
   }
-  return v;
+}
+// sorted (descending) 64-lane sequence from a bitonic one: the merge half of the network
+__device__ __forceinline__ void shard_bitonic_merge64_desc(u64& key, long long& idv, int lane) {
+#pragma unroll
+  for (int stride = 32; stride > 0; stride >>= 1) cx64(key, idv, stride, (lane & stride) == 0);
 }
 
 template <bool STAGED>
@@ -78,20 +98,34 @@ __global__ __launch_bounds__(256) void shard_merge_kernel(ShardLayout L, int wor
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long w = (long)blockIdx.x * 4 + wave;
   if (w >= (long)nq * L.n) return;
-  const int q = (int)(w / L.n), ch = (int)(w - (long)q * L.n);
-  const int k = L.k[ch], col = L.col[ch], total = world * k;
-  C64 best;      // lane j < k: the j-th hit
-  int got = k;   // results beyond `got` are padding (fast paths: decided per lane by is_pad)
+  const int q = (int)(w / L.n), ch = __builtin_amdgcn_readfirstlane((int)(w - (long)q * L.n));  // wave-uniform
+  const int k = SHARD_PICK(L.k, ch), col = SHARD_PICK(L.col, ch), total = world * k;
+  const bool f64 = SHARD_PICK(L.f64, ch) != 0;
+  void* osp = SHARD_PICK(L.out_scores, ch);
+  long long* oip = SHARD_PICK(L.out_ids, ch);
+  u64 bkey = 0ull;  // lane j < k: the j-th hit
+  long long bid = 0;
   if (!STAGED || (total <= 128 && k <= 64)) {
-    C64 a = shard_cand(g, nq, L.row, q, col, k, lane, total);
-    a = wave_sort64_desc(a, lane);
+    const C64 a = shard_cand(g, nq, L.row, q, col, k, lane, total);
+    bkey = a.key, bid = a.idv;
+    shard_sort64_desc(bkey, bid, lane);
     if (total > 64) {
-      C64 b = shard_cand(g, nq, L.row, q, col, k, 64 + lane, total);
-      b = wave_sort64_desc(b, lane);
-      const C64 br = wave_xchg(b, 63 - lane);            // b reversed: max(a[l], b[63 - l]) is the top 64 of the union,
-      a = wave_bitonic_merge64_desc(better(a, br) ? a : br, lane);  // as a bitonic sequence
+      const C64 b = shard_cand(g, nq, L.row, q, col, k, 64 + lane, total);
+      u64 k2 = b.key;
+      long long i2 = b.idv;
+      shard_sort64_desc(k2, i2, lane);
+      // the second half reversed (lane l <-> 63 - l = every stride flipped): max(a[l], b[63 - l]) is the top 64 of the
+      // union as a bitonic sequence
+#pragma unroll
+      for (int st = 1; st < 64; st <<= 1) {
+        k2 = lane_xor_sw(k2, st);
+        i2 = (long long)lane_xor_sw((u64)i2, st);
+      }
+      const bool mine = bkey > k2 || (bkey == k2 && bid < i2);
+      bkey = mine ? bkey : k2;
+      bid = mine ? bid : i2;
+      shard_bitonic_merge64_desc(bkey, bid, lane);
     }
-    best = a;
   } else {
     C64* buf = reinterpret_cast<C64*>(smem) + (size_t)wave * cap;
     WaveTopK<C64> tk;
@@ -101,25 +135,25 @@ __global__ __launch_bounds__(256) void shard_merge_kernel(ShardLayout L, int wor
       tk.push_lanes(c, !c.is_pad(), lane);
     }
     tk.finalize(lane);
-    got = tk.cnt;
+    const int got = tk.cnt;
     for (int j = lane; j < k; j += 64) {
       const C64 c = j < got ? buf[j] : C64::pad();
       const bool v = !c.is_pad();
-      if (L.f64[ch])
-        reinterpret_cast<double*>(L.out_scores[ch])[(size_t)q * k + j] = v ? unord64(c.key) : -DBL_MAX;
+      if (f64)
+        reinterpret_cast<double*>(osp)[(size_t)q * k + j] = v ? unord64(c.key) : -DBL_MAX;
       else
-        reinterpret_cast<float*>(L.out_scores[ch])[(size_t)q * k + j] = v ? (float)unord64(c.key) : -FLT_MAX;
-      L.out_ids[ch][(size_t)q * k + j] = v ? c.idv : -1ll;
+        reinterpret_cast<float*>(osp)[(size_t)q * k + j] = v ? (float)unord64(c.key) : -FLT_MAX;
+      oip[(size_t)q * k + j] = v ? c.idv : -1ll;
     }
     return;
   }
   if (lane < k) {
-    const bool v = !best.is_pad();
-    if (L.f64[ch])
-      reinterpret_cast<double*>(L.out_scores[ch])[(size_t)q * k + lane] = v ? unord64(best.key) : -DBL_MAX;
+    const bool v = bkey != 0ull;
+    if (f64)
+      reinterpret_cast<double*>(osp)[(size_t)q * k + lane] = v ? unord64(bkey) : -DBL_MAX;
     else
-      reinterpret_cast<float*>(L.out_scores[ch])[(size_t)q * k + lane] = v ? (float)unord64(best.key) : -FLT_MAX;
-    L.out_ids[ch][(size_t)q * k + lane] = v ? best.idv : -1ll;
+      reinterpret_cast<float*>(osp)[(size_t)q * k + lane] = v ? (float)unord64(bkey) : -FLT_MAX;
+    oip[(size_t)q * k + lane] = v ? bid : -1ll;
   }
 }
 

@@ -65,6 +65,7 @@ class HybridEngine:
         self.tdev = torch.device("cuda", self.device)
         self.maps = (dense_row2uid, bm25_row2uid, colbert_row2uid)
         self._bufs = {}
+        self._xcache = {}  # argument blocks of the shard exchange (sharding.exchange_topk_native)
         # Row-sharded corpus (retrieval/sharding.py): the three indexes hold this rank's row block (local ids
         # 0 .. n_r - 1 = global ids shard_offset ..); search_batch then all-gathers the packed per-channel lists
         # ONCE per batch, merges W*k -> k per channel (merge_parts_kernel) and fuses the GLOBAL lists — the
@@ -191,7 +192,8 @@ class HybridEngine:
         if self.shard_offset is not None:
             from . import sharding
             chans = [x for x in (d, b, c) if x is not None]
-            merged = iter(sharding.exchange_topk(chans, int(self.shard_offset), group=self.shard_group, buf=self._buf))
+            merged = iter(sharding.exchange_topk(chans, int(self.shard_offset), group=self.shard_group, buf=self._buf,
+                                                 cache=self._xcache))
             d, b, c = (next(merged) if x is not None else None for x in (d, b, c))
         res = self.fuse(params, nq, d, b, c)
         if d is not None:

@@ -109,40 +109,51 @@ def native_merge(scores: torch.Tensor, ids: torch.Tensor, k_out: int):
 
 
 def exchange_topk_native(chans: Sequence[Tuple[torch.Tensor, torch.Tensor]], offset: int, *, group=None,
-                         buf: Optional[Callable] = None):
+                         buf: Optional[Callable] = None, cache: Optional[dict] = None):
     """The product form of the exchange for device-resident lists: ONE pack launch (amdr_shard_pack_device: every
     channel's score bits + global ids straight into the all-gather's send buffer), the all-gather, ONE merge launch
     (amdr_shard_merge_device: reads the gathered buffer in place, all channels).  `buf(name, shape, dtype)` supplies
-    persistent buffers (HybridEngine._buf: no allocation per call); default: fresh tensors."""
+    persistent buffers (HybridEngine._buf: no allocation per call); `cache` (a dict the caller keeps) remembers the
+    argument blocks of the two native calls per set of input tensors, so a steady-state call is two ctypes calls
+    and the collective."""
     dev = chans[0][0].device
     nq = int(chans[0][0].shape[0])
-    for s, i in chans:
-        if not (s.is_cuda and i.is_cuda and s.is_contiguous() and i.is_contiguous() and i.dtype == torch.int64
-                and s.dtype in (torch.float32, torch.float64) and s.shape == i.shape and s.shape[0] == nq):
-            raise ValueError("exchange_topk_native: channels must be contiguous CUDA (scores f32|f64, ids i64) [nq, k]")
-    mk = buf or (lambda name, shape, dtype: torch.empty(shape, dtype=dtype, device=dev))
-    ks = [int(i.shape[1]) for _, i in chans]
-    row = sum(2 * k for k in ks)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
+    key = (tuple((s.data_ptr(), i.data_ptr(), tuple(s.shape), s.dtype) for s, i in chans), int(offset), world)
+    plan = cache.get(key) if cache is not None else None
+    if plan is None:
+        for s, i in chans:
+            if not (s.is_cuda and i.is_cuda and s.is_contiguous() and i.is_contiguous() and i.dtype == torch.int64
+                    and s.dtype in (torch.float32, torch.float64) and s.shape == i.shape and s.shape[0] == nq):
+                raise ValueError("exchange_topk_native: channels must be contiguous CUDA (scores f32|f64, ids i64) [nq, k]")
+        mk = buf or (lambda name, shape, dtype: torch.empty(shape, dtype=dtype, device=dev))
+        ks = [int(i.shape[1]) for _, i in chans]
+        row = _native.shard_row_words(ks)
+        send = mk("xsend", (nq, row), torch.int64)
+        gathered = send if world == 1 else mk("xrecv", (world * nq, row), torch.int64)
+        out = [(mk(f"xs{c}", (nq, k), s.dtype), mk(f"xi{c}", (nq, k), torch.int64))
+               for c, ((s, _), k) in enumerate(zip(chans, ks))]
+        pack_args = _native.shard_chans([(s.data_ptr(), i.data_ptr(), k, s.dtype == torch.float64)
+                                         for (s, i), k in zip(chans, ks)])
+        merge_args = _native.shard_chans([(os_.data_ptr(), oi.data_ptr(), k, os_.dtype == torch.float64)
+                                          for (os_, oi), k in zip(out, ks)])
+        plan = (pack_args, merge_args, send, gathered, out, list(chans))  # (the inputs kept alive with their pointers)
+        if cache is not None:
+            if len(cache) > 64:
+                cache.clear()
+            cache[key] = plan
+    pack_args, merge_args, send, gathered, out, _ = plan
     stream = int(torch.cuda.current_stream(dev).cuda_stream)
     di = dev.index or 0
-    send = mk("xsend", (nq, row), torch.int64)
-    _native.shard_pack_device([(s.data_ptr(), i.data_ptr(), k, s.dtype == torch.float64) for (s, i), k in zip(chans, ks)],
-                              nq, int(offset), send.data_ptr(), device=di, stream=stream)
-    if world == 1:
-        gathered = send
-    else:
-        gathered = mk("xrecv", (world * nq, row), torch.int64)
+    _native.shard_pack_args(pack_args, nq, int(offset), send.data_ptr(), device=di, stream=stream)
+    if world > 1:
         dist.all_gather_into_tensor(gathered, send, group=group)
-    out = [(mk(f"xs{c}", (nq, k), s.dtype), mk(f"xi{c}", (nq, k), torch.int64)) for c, ((s, _), k) in enumerate(zip(chans, ks))]
-    _native.shard_merge_device(gathered.data_ptr(), world, nq,
-                               [(os_.data_ptr(), oi.data_ptr(), k, os_.dtype == torch.float64) for (os_, oi), k in zip(out, ks)],
-                               device=di, stream=stream)
+    _native.shard_merge_args(gathered.data_ptr(), world, nq, merge_args, device=di, stream=stream)
     return out
 
 
 def exchange_topk(chans: Sequence[Tuple[torch.Tensor, torch.Tensor]], offset: int, *, group=None,
-                  merge_fn: Optional[Callable] = None, buf: Optional[Callable] = None):
+                  merge_fn: Optional[Callable] = None, buf: Optional[Callable] = None, cache: Optional[dict] = None):
     """All-gather the local per-channel top-k of this rank's shard and merge.
 
     chans: [(scores[nq,k_c], LOCAL ids[nq,k_c])].  Returns the same structure
@@ -150,7 +161,8 @@ def exchange_topk(chans: Sequence[Tuple[torch.Tensor, torch.Tensor]], offset: in
     launches (exchange_topk_native); the torch form below is what the CPU tests drive with an injected checker
     merge (the product has no CPU merge)."""
     if merge_fn is None and chans and all(s.is_cuda and i.is_cuda for s, i in chans) and len(chans) <= 4:
-        return exchange_topk_native([(s.contiguous(), i.contiguous()) for s, i in chans], offset, group=group, buf=buf)
+        return exchange_topk_native([(s.contiguous(), i.contiguous()) for s, i in chans], offset, group=group, buf=buf,
+                                    cache=cache)
     merge_fn = merge_fn or native_merge
     ks = [int(i.shape[1]) for _, i in chans]
     dts = [s.dtype for s, _ in chans]

@@ -41,7 +41,8 @@ def main():
             if key not in bufs:
                 bufs[key] = torch.empty(shape, dtype=dtype, device=dev)
             return bufs[key]
-        native = timed(lambda: sharding.exchange_topk(chans, 1000, buf=buf))
+        xc = {}
+        native = timed(lambda: sharding.exchange_topk(chans, 1000, buf=buf, cache=xc))
         torch_form = timed(lambda: sharding.exchange_topk(chans, 1000, merge_fn=sharding.native_merge), iters=50, warm=5)
         out[f"{nq}x3x{k}"] = {"native_pack_plus_merge_us": round(native, 2), "torch_form_us": round(torch_form, 2)}
     print(json.dumps({"exchange_topk_world1": out}))
