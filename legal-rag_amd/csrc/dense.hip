@@ -624,7 +624,7 @@ void hi2_plan(const amdr_dense* h, int m, int k, int kc, Hi2Plan* p) {
   p->qcap = dense_hi2_qcap((long)h->n, p->qtiles, kc);
   p->off_S2 = up((size_t)m * p->ldM * sizeof(float));
   p->off_MT = p->off_S2 + up((size_t)m * p->ldS2 * sizeof(float));
-  p->off_qlist = p->off_MT + up((size_t)(2048 + 64) * 64 * sizeof(float));  // qtiles x items <= 2 048 + 8 qtiles
+  p->off_qlist = p->off_MT + up((size_t)(2048 + 64 * kHi2Tiles) * 64 * sizeof(float));  // [queries][items rounded up to 64]
   p->smat_bytes = p->off_qlist + up((size_t)m * p->qcap * sizeof(C32));
   p->off_count = up((size_t)m * kc * sizeof(int));
   p->off_unres = p->off_count + up((size_t)m * sizeof(int));

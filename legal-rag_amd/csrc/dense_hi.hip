@@ -86,11 +86,42 @@ __global__ __launch_bounds__(kHiWaves * 64) void dense_hi_tilemax_kernel(const f
   const int r32 = lane & 31, h = lane >> 5;
 
   // grid.y > 1 (the sample of a multi-tile search): block row y works for query tile y
+  // round 4 (sample only): em.tau_stride < 0 asks for the query-major layout MT[query][ld = -tau_stride] (one 4-byte store
+  // per (item, query); the threshold kernel then reads a query's row with coalesced loads: 27 -> 6 us)
+  const long q_ld = (!EMIT && em.tau_stride < 0) ? -(long)em.tau_stride : 0;
   if (gridDim.y > 1) {
     Q += (size_t)blockIdx.y * QT * d;
     nq -= (int)blockIdx.y * QT;
     nq = nq < 0 ? 0 : (nq > QT ? QT : nq);
-    MT += (size_t)blockIdx.y * n_items * cols;
+    MT += q_ld ? (size_t)blockIdx.y * QT * q_ld : (size_t)blockIdx.y * n_items * cols;
+  }
+  // The wave's first two chunks of X are requested BEFORE the query tile is converted (they do not depend on it): the
+  // two memory round trips at the head of every launch overlap instead of following each other.
+  // Persistent block (one per CU: the query tile is converted once).  Every wave of the grid owns one contiguous run
+  // of tiles (run lengths differ by at most one tile) and streams it front to back; its loads run two 64-float chunks
+  // ahead, across tile boundaries.
+  const long gw = (long)blockIdx.x * kHiWaves + wave, nw = (long)gridDim.x * kHiWaves;
+  const long t_lo = n_items * gw / nw, t_hi = n_items * (gw + 1) / nw;  // this wave's run of items
+  // loader role inside a 1-KiB piece: 4 rows x 256 B; lane: row l >> 4, 16-B piece l & 15 (4 floats)
+  const int lrow = lane >> 4, lpiece = lane & 15;
+  auto row_ptr = [&](long item, int p) {
+    long r = item * tile_stride * 32 + 4 * p + lrow;
+    if (r >= n) r = n - 1;  // rows past the end repeat the last row: no effect on a maximum
+    return X + (size_t)r * d + lpiece * 4;
+  };
+  hi4f G[2][8];
+  const float* gpn[8];
+  if (t_lo < t_hi) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) gpn[p] = row_ptr(t_lo, p);
+    // issue order = the steady state's (chunk 0's loads, then chunk 1's): the loop header's vmcnt waits are the
+    // minimum over this entry and the back edge, an interleaved order here would drain the queue at every tile start
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+      for (int p = 0; p < 8; ++p) G[c][p] = __builtin_nontemporal_load(reinterpret_cast<const hi4f*>(gpn[p] + c * kHiKC));
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   // ---- the query tile: wave w converts queries 8 w .. 8 w + 7 (scale = 2^-e of the query's largest |component|).
   // Lane l owns the 16-byte fp16 chunks l and l + 64 of a query (8 consecutive components each: two 16-byte loads, one
@@ -155,32 +186,6 @@ __global__ __launch_bounds__(kHiWaves * 64) void dense_hi_tilemax_kernel(const f
   }
   __syncthreads();
 
-  // Persistent block (one per CU: the query tile is converted once).  Every wave of the grid owns one contiguous run
-  // of tiles (run lengths differ by at most one tile) and streams it front to back; its loads run two 64-float chunks
-  // ahead, across tile boundaries.
-  const long gw = (long)blockIdx.x * kHiWaves + wave, nw = (long)gridDim.x * kHiWaves;
-  const long t_lo = n_items * gw / nw, t_hi = n_items * (gw + 1) / nw;  // this wave's run of items
-  // loader role inside a 1-KiB piece: 4 rows x 256 B; lane: row l >> 4, 16-B piece l & 15 (4 floats)
-  const int lrow = lane >> 4, lpiece = lane & 15;
-  auto row_ptr = [&](long item, int p) {
-    long r = item * tile_stride * 32 + 4 * p + lrow;
-    if (r >= n) r = n - 1;  // rows past the end repeat the last row: no effect on a maximum
-    return X + (size_t)r * d + lpiece * 4;
-  };
-  hi4f G[2][8];
-  const float* gpn[8];
-  if (t_lo < t_hi) {
-#pragma unroll
-    for (int p = 0; p < 8; ++p) gpn[p] = row_ptr(t_lo, p);
-    // issue order = the steady state's (chunk 0's loads, then chunk 1's): the loop header's vmcnt waits are the
-    // minimum over this entry and the back edge, an interleaved order here would drain the queue at every tile start
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-#pragma unroll
-      for (int p = 0; p < 8; ++p) G[c][p] = __builtin_nontemporal_load(reinterpret_cast<const hi4f*>(gpn[p] + c * kHiKC));
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
   float mt[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) mt[j] = 0.f;
@@ -287,6 +292,8 @@ __global__ __launch_bounds__(kHiWaves * 64) void dense_hi_tilemax_kernel(const f
         wcnt += __popcll(pm);
         if (wcnt + 64 > em.wbuf) flush();
       }
+    } else if (q_ld) {
+      if (lane < nq) MT[(size_t)lane * q_ld + t] = mine;
     } else {
       // MT[item][cols], cols = the queries rounded up to 16: one contiguous row per item, the maxima of 8 items collected
       // in registers and written as 8 back-to-back row stores.
@@ -645,13 +652,13 @@ __global__ __launch_bounds__(64) void dense_hi_tau_kernel(const float* __restric
                                                           int* __restrict__ flag, unsigned int* __restrict__ stats,
                                                           int qtiles) {
   const int q = blockIdx.x, lane = threadIdx.x;
-  const int y = q / qt, c = q - y * qt;
-  const float* col = MT + (size_t)y * items * cols + c;
+  const float* row = MT + (size_t)q * cols;  // query-major: row q, `cols` = its leading dimension (items rounded up to 64)
+  (void)qt;
   u32 key[32];
 #pragma unroll
   for (int v = 0; v < 32; ++v) {
     const int i = lane + 64 * v;
-    key[v] = i < items ? ord32(col[(size_t)i * cols]) : 0u;
+    key[v] = i < items ? ord32(row[i]) : 0u;
   }
   u32 K = 0u;
 #pragma unroll 1
@@ -675,6 +682,17 @@ __global__ __launch_bounds__(64) void dense_hi_tau_kernel(const float* __restric
   }
 }
 
+template <int V>
+__device__ __forceinline__ int select_list(const C32* __restrict__ src, unsigned int n, int k, int lane, C32* buf) {
+  C32 keys[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const unsigned int i = lane + 64u * v;
+    keys[v] = i < n ? src[i] : C32::pad();
+  }
+  return wave_select_small<C32, V>(keys, k, buf + 64, lane, buf);
+}
+
 // One block per query: (1) the kc best entries of the query's candidate list (score desc, tile asc — the order of every
 // top-k here); (2) the check of dense_hi_check_kernel: is every tile that can hold one of the k best rows among them?
 // (3) resolved -> the tiles at or above the cut T_k - 2 eps, ASCENDING, into list[q * kc ..], count[q]; unresolved ->
@@ -696,20 +714,45 @@ __global__ __launch_bounds__(256) void dense_hi_select_kernel(const C32* __restr
   const C32* src = qlist + (size_t)q * qcap;
   WaveTopK<C32> tk;
   tk.init(lists + (size_t)wave * tcap, tcap, kc1);
-  constexpr int UN = 4;  // entries per lane requested before the first is looked at
-  for (unsigned int base = (unsigned int)wave * 64; base < n; base += 256 * UN) {
-    C32 e[UN];
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const unsigned int i = base + 256 * u + lane;
-      e[u] = i < n ? src[i] : C32::pad();
+  // Short lists (the usual case: ~kc x sample stride entries) are ranked by ONE wave in registers (topk.hpp
+  // wave_select_small: lane bests, their kc-th as the cut, the few survivors sorted) — the staged selector's LDS sorts
+  // (two or three per wave, then three merges) were 25 of this kernel's 32 us.  Mass ties at the cut (> 64 survivors),
+  // long lists and wide cuts take the staged selector on all four waves.
+  int got = -1;
+  if (n <= 2048u && kc1 <= 64) {  // block-uniform
+    if (wave != 0) return;
+    if (n <= 512u)
+      got = select_list<8>(src, n, kc1, lane, tk.buf);
+    else if (n <= 1024u)
+      got = select_list<16>(src, n, kc1, lane, tk.buf);
+    else
+      got = select_list<32>(src, n, kc1, lane, tk.buf);
+    if (got >= 0) {
+      tk.cnt = got;
+    } else {  // mass ties: this wave alone, staged
+      for (unsigned int base = 0; base < n; base += 64) {
+        const unsigned int i = base + lane;
+        const C32 e = i < n ? src[i] : C32::pad();
+        tk.push_lanes(e, !e.is_pad(), lane);
+      }
+      tk.finalize(lane);
     }
+  } else {
+    constexpr int UN = 4;  // entries per lane requested before the first is looked at
+    for (unsigned int base = (unsigned int)wave * 64; base < n; base += 256 * UN) {
+      C32 e[UN];
 #pragma unroll
-    for (int u = 0; u < UN; ++u) tk.push_lanes(e[u], !e[u].is_pad(), lane);
+      for (int u = 0; u < UN; ++u) {
+        const unsigned int i = base + 256 * u + lane;
+        e[u] = i < n ? src[i] : C32::pad();
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) tk.push_lanes(e[u], !e[u].is_pad(), lane);
+    }
+    tk.finalize(lane);
+    block_combine_topk(tk, lists, tcap, 4, wave, lane, cnts);
+    if (wave != 0) return;
   }
-  tk.finalize(lane);
-  block_combine_topk(tk, lists, tcap, 4, wave, lane, cnts);
-  if (wave != 0) return;
   // ---- the rounding bound of this query (dense_hi_check_kernel states it)
   float amax = 0.f;
   bool nan = false;
@@ -834,16 +877,18 @@ size_t dense_hi2_qcap(long n, int qtiles, int kc) {
   const size_t all = (size_t)((n + 31) / 32);
   return e < all ? e : all;
 }
+long dense_hi2_sample_ld(long n, int qtiles) { return (dense_hi2_sample_items(n, qtiles) + 63) / 64 * 64; }
 int dense_hi2_launch_sample(const float* X, long n, int d, const float* Q, int nq, int qtiles, float* MT, hipStream_t st,
                             float x_scale) {
   HiEmit em{};
+  em.tau_stride = -(int)dense_hi2_sample_ld(n, qtiles);  // query-major maxima: MT[query][ld]
   return launch_hi_d<false>(X, n, d, Q, nq, MT, x_scale, dense_hi2_sample_stride(n, qtiles), em, st, qtiles);
 }
 int dense_hi2_launch_tau(const float* MT, long n, int d, int nq, int qtiles, int kc, float* tau, unsigned int* qcount,
                          int* flag, unsigned int* stats, hipStream_t st) {
   const int items = (int)dense_hi2_sample_items(n, qtiles);
   if (items > 2048) return fail(AMDR_EINVAL, "dense (fp16 first pass): %d sample items", items);
-  hipLaunchKernelGGL(dense_hi_tau_kernel, dim3(nq), dim3(64), 0, st, MT, items, qtiles > 1 ? 64 : hi_mt_cols(nq),
+  hipLaunchKernelGGL(dense_hi_tau_kernel, dim3(nq), dim3(64), 0, st, MT, items, (int)dense_hi2_sample_ld(n, qtiles),
                      hi_query_tile(d), kc, tau, qcount, flag, stats, qtiles);
   AMDR_HIP(hipGetLastError());
   return AMDR_OK;

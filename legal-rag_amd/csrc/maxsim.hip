@@ -877,7 +877,7 @@ __global__ __launch_bounds__(64) void maxsim_select_kernel(const float* __restri
                                                            float d_norm_max, float unscale_d, int cap,
                                                            float* __restrict__ exact /*[nq, n_docs]*/,
                                                            int* __restrict__ cand /*[nq, cap]*/, int* __restrict__ cnt,
-                                                           int* __restrict__ overflow) {
+                                                           int* __restrict__ overflow, int* __restrict__ dcnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   C32* buf = reinterpret_cast<C32*>(smem);
   const int lane = threadIdx.x, q = blockIdx.x;
@@ -926,6 +926,12 @@ __global__ __launch_bounds__(64) void maxsim_select_kernel(const float* __restri
   if (lane == 0) {
     overflow[q] = n > cap ? 1 : 0;
     cnt[q] = n > cap ? 0 : n;
+  }
+  if (dcnt != nullptr && n <= cap) {  // round 4: the re-scoring pass walks the pairs by document
+    for (long base = 0; base < n_docs; base += 64) {
+      const long d = base + lane;
+      if (d < n_docs && (row[d] >= thr || thr == -FLT_MAX)) atomicAdd(dcnt + d, 1);
+    }
   }
 }
 
@@ -1037,6 +1043,146 @@ __global__ __launch_bounds__(256) void maxsim_rescore_kernel(const unsigned char
   }
 }
 
+// ---- Pass 2, round 4: the candidate pairs grouped BY DOCUMENT ------------------------------------------------------
+// One wave per pair shared nothing: 15 k pairs x a document image of ~80 KB = 0.93 GB through the fabric for 68 MB of
+// token store (PMC, profiles/r03_pmc.md), 145 us.  A document is a candidate of ~25 queries on the serving corpora, so
+// the pairs are inverted to per-document query lists and a block takes (document, 8 of its queries): the document's
+// tiles go ONCE through the block's LDS ring (the one-pass ring kernel's, same fragments, same tile function: the same
+// bits) and feed 8 queries' MFMAs.
+//   maxsim_select_kernel        also counts the candidates of every document (dcnt)
+//   maxsim_doc_offsets_kernel   exclusive prefix sums over the documents: pairs (doff) and 8-query items (ioff)
+//   maxsim_pairs_fill_kernel    pairs[doff[doc] + slot] = query
+//   maxsim_rescore_ring_kernel  persistent blocks of 8 waves walk the items
+__global__ __launch_bounds__(256) void maxsim_doc_offsets_kernel(const int* __restrict__ dcnt, long n_docs,
+                                                                 int* __restrict__ doff, int* __restrict__ ioff) {
+  __shared__ int part[2][256];
+  int carry_p = 0, carry_i = 0;
+  for (long base = 0; base < n_docs; base += 256) {
+    const long i = base + threadIdx.x;
+    const int v = i < n_docs ? dcnt[i] : 0;
+    const int it = (v + kMsQ - 1) / kMsQ;
+    part[0][threadIdx.x] = v;
+    part[1][threadIdx.x] = it;
+    __syncthreads();
+    for (int sft = 1; sft < 256; sft <<= 1) {
+      const int o0 = threadIdx.x >= sft ? part[0][threadIdx.x - sft] : 0;
+      const int o1 = threadIdx.x >= sft ? part[1][threadIdx.x - sft] : 0;
+      __syncthreads();
+      part[0][threadIdx.x] += o0;
+      part[1][threadIdx.x] += o1;
+      __syncthreads();
+    }
+    if (i < n_docs) {
+      doff[i] = carry_p + part[0][threadIdx.x] - v;
+      ioff[i] = carry_i + part[1][threadIdx.x] - it;
+    }
+    carry_p += part[0][255];
+    carry_i += part[1][255];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    doff[n_docs] = carry_p;
+    ioff[n_docs] = carry_i;
+  }
+}
+
+__global__ __launch_bounds__(256) void maxsim_pairs_fill_kernel(const int* __restrict__ cand, const int* __restrict__ cnt,
+                                                                int nq, int cap, const int* __restrict__ doff,
+                                                                int* __restrict__ dfill, int* __restrict__ pairs) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)nq * cap) return;
+  const int q = (int)(idx / cap), j = (int)(idx - (long)q * cap);
+  if (j >= cnt[q]) return;
+  const int doc = cand[idx];
+  pairs[doff[doc] + atomicAdd(dfill + doc, 1)] = q;  // the order inside a document's list does not matter
+}
+
+template <int NBUF>
+__global__ __launch_bounds__(kMsQ * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void maxsim_rescore_ring_kernel(
+    const unsigned char* __restrict__ img, const long long* __restrict__ doc_ptr, long n_docs,
+    const float* __restrict__ Q, int q_len, float unscale_d, const int* __restrict__ doff, const int* __restrict__ ioff,
+    const int* __restrict__ pairs, float* __restrict__ exact /*[nq, n_docs]*/) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // [NBUF][32 * 512]
+  constexpr int kStage = 32 * 512;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r32 = lane & 31, h = lane >> 5;
+  long poff[2];  // DMA role of this wave: pieces 2 wave, 2 wave + 1 of a tile (maxsim_scores_ring_kernel)
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int prow = 2 * (2 * wave + u) + (lane >> 5);
+    poff[u] = (long)prow * 512 + (((lane & 31) ^ (prow & 15)) << 4);
+  }
+  int foff[8];
+#pragma unroll
+  for (int st = 0; st < 8; ++st) foff[st] = ms_tile_off(r32, 2 * st + h);
+  const int items = ioff[n_docs];
+  for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    long doc;
+    {  // the document of this item: the last d with ioff[d] <= item (documents without candidates share their successor's offset)
+      long a = 0, b = n_docs;
+      while (b - a > 1) {
+        const long m = (a + b) >> 1;
+        if (ioff[m] <= item) a = m; else b = m;
+      }
+      doc = a;
+    }
+    const int p0 = doff[doc] + (item - ioff[doc]) * kMsQ, p1 = doff[doc + 1];
+    const bool live = p0 + wave < p1;
+    const int qi = live ? pairs[p0 + wave] : 0;
+    ms8h qh[8], ql[8];
+    float unscale;
+    ms_load_query_h(Q + (size_t)qi * q_len * kDim, q_len, live, r32, h, qh, ql, unscale);
+    unscale *= unscale_d;
+    const long t_lo = doc_ptr[doc];
+    const int len = (int)(doc_ptr[doc + 1] - t_lo);
+    const int ntiles = (len + 31) >> 5;
+    // every wave has read the last tile of the previous item before its stage is refilled
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int issued = 0;
+    auto issue = [&](int tile) {
+      const unsigned char* src = img + (size_t)(t_lo + 32 * tile) * 512;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        __builtin_amdgcn_global_load_lds(AMDR_MS_GPTR(src + poff[u]),
+                                         AMDR_MS_LPTR(ring + (tile % NBUF) * kStage + (2 * wave + u) * 1024), 16, 0, 0);
+    };
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i)
+      if (issued < ntiles) issue(issued++);
+    float best = -FLT_MAX;
+    for (int done = 0; done < ntiles; ++done) {
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+      const int behind = issued - done - 1;
+      if (behind >= 3) {
+        __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(6)
+      } else if (behind == 2) {
+        __builtin_amdgcn_s_waitcnt(0x0F74);
+      } else if (behind == 1) {
+        __builtin_amdgcn_s_waitcnt(0x0F72);
+      } else {
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (issued < ntiles) issue(issued++);
+      const unsigned char* tile = ring + (done % NBUF) * kStage;
+      ms8h ah[8], al[8];
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        const unsigned char* fp = tile + foff[st];
+        ah[st] = *reinterpret_cast<const ms8h*>(fp);
+        al[st] = *reinterpret_cast<const ms8h*>(fp + 256);
+      }
+      ms_tile_h(ah, al, qh, ql, h, len - 32 * done, best);
+    }
+    const float total = ms_finish_h(best, r32, h, q_len, unscale);
+    if (live && lane == 0) exact[(size_t)qi * n_docs + doc] = total;
+  }
+}
+
 // a query whose candidate list overflowed: every document, full form (rare: mass near-ties at the cut)
 __global__ __launch_bounds__(256) void maxsim_overflow_kernel(const unsigned char* __restrict__ img,
                                                               const long long* __restrict__ doc_ptr, long n_docs,
@@ -1124,7 +1270,9 @@ int ms_cand_cap(int k) {
 size_t ms_workspace_bytes(const amdr_maxsim* h, int nq, int k, bool want_topk) {
   const size_t rows = ((size_t)nq * h->n_docs * sizeof(float) + 255) / 256 * 256;
   if (!ms_two_pass(h, nq, k, want_topk)) return rows;
-  return 2 * rows + ((size_t)nq * ms_cand_cap(k) + 3 * (size_t)nq + 1) * sizeof(int) + 256;
+  // + the by-document pair lists of the re-scoring pass: pairs [nq * cap], dcnt / dfill [n_docs] each, doff / ioff [n_docs + 1]
+  return 2 * rows + ((size_t)nq * ms_cand_cap(k) + 3 * (size_t)nq + 1) * sizeof(int) + 256 +
+         ((size_t)nq * ms_cand_cap(k) + 4 * (size_t)h->n_docs + 8) * sizeof(int);
 }
 
 int ms_run(amdr_maxsim* h, const float* Q_dev, int nq, int q_len, int k, float* full_dev, float* scores_dev,
@@ -1159,18 +1307,37 @@ int ms_run(amdr_maxsim* h, const float* Q_dev, int nq, int q_len, int k, float* 
                          q_len, approx, unscale_d);
     }
     const int cap_sel = topk_cap(k);
+    int* off = ovf + nq;                      // [nq + 1] (round-3 form)
+    int* pairs = off + nq + 1;                // round 4: [nq * cap] queries, grouped by document
+    int* dcnt = pairs + (size_t)nq * cap;     // [n_docs] candidates per document, then dfill [n_docs]
+    int* dfill = dcnt + h->n_docs;
+    int* doff = dfill + h->n_docs;            // [n_docs + 1] first pair of a document
+    int* ioff = doff + h->n_docs + 1;         // [n_docs + 1] first 8-query item of a document
+    const char* rs = getenv("AMDR_MAXSIM_RESCORE");  // "0": one wave per pair (the round-3 form; A/B, tests)
+    const bool by_doc = !(rs && rs[0] == '0');
+    if (by_doc) AMDR_HIP(hipMemsetAsync(dcnt, 0, 2 * (size_t)h->n_docs * sizeof(int), st));
     hipLaunchKernelGGL(maxsim_select_kernel, dim3(nq), dim3(64), (size_t)cap_sel * sizeof(C32), st, approx,
-                       (long)h->n_docs, Q_dev, q_len, k, cap_sel, h->d_norm_max, unscale_d, cap, exact, cand, cnt, ovf);
+                       (long)h->n_docs, Q_dev, q_len, k, cap_sel, h->d_norm_max, unscale_d, cap, exact, cand, cnt, ovf,
+                       by_doc ? dcnt : (int*)nullptr);
     constexpr int kPairLds = kMsWaves * 16384;
-    AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_rescore_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds));
     AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_overflow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds));
-    int* off = ovf + nq;
-    hipLaunchKernelGGL(maxsim_offsets_kernel, dim3(1), dim3(256), 0, st, cnt, nq, off);
     int dev = 0, cus = 256;
     AMDR_HIP(hipGetDevice(&dev));
     AMDR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    hipLaunchKernelGGL(maxsim_rescore_kernel, dim3(2 * cus), dim3(256), kPairLds, st, h->img, h->doc_ptr, (long)h->n_docs,
-                       Q_dev, nq, q_len, unscale_d, cand, off, cap, exact);
+    if (by_doc) {
+      hipLaunchKernelGGL(maxsim_doc_offsets_kernel, dim3(1), dim3(256), 0, st, dcnt, (long)h->n_docs, doff, ioff);
+      hipLaunchKernelGGL(maxsim_pairs_fill_kernel, dim3(ceil_div((long)nq * cap, 256)), dim3(256), 0, st, cand, cnt, nq, cap,
+                         doff, dfill, pairs);
+      AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_rescore_ring_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   4 * 16384));
+      hipLaunchKernelGGL((maxsim_rescore_ring_kernel<4>), dim3(2 * cus), dim3(kMsQ * 64), 4 * 16384, st, h->img, h->doc_ptr,
+                         (long)h->n_docs, Q_dev, q_len, unscale_d, doff, ioff, pairs, exact);
+    } else {
+      AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_rescore_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds));
+      hipLaunchKernelGGL(maxsim_offsets_kernel, dim3(1), dim3(256), 0, st, cnt, nq, off);
+      hipLaunchKernelGGL(maxsim_rescore_kernel, dim3(2 * cus), dim3(256), kPairLds, st, h->img, h->doc_ptr, (long)h->n_docs,
+                         Q_dev, nq, q_len, unscale_d, cand, off, cap, exact);
+    }
     hipLaunchKernelGGL(maxsim_overflow_kernel, dim3(nq), dim3(256), kPairLds, st, h->img, h->doc_ptr, (long)h->n_docs,
                        Q_dev, q_len, unscale_d, ovf, exact);
     AMDR_HIP(hipGetLastError());

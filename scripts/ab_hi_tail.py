@@ -66,6 +66,10 @@ def main():
     Q = bench.synth_queries(torch, dev, d)
     cases = [tuple(int(v) for v in c.split(":")) for c in os.environ.get("AB_CASES", "64:10,256:10,32:10,64:40").split(",")]
     for B, k in cases:
+        if os.environ.get("AB_ONLY"):  # one form only (whatever AMDR_DENSE_HI_TAIL the caller pinned): profiling runs
+            o, _ = run(X, Q, n, d, B, k, steps, {})
+            print(json.dumps(o), flush=True)
+            continue
         ex, rx = run(X, Q, n, d, B, k, max(3, steps // 6), {"AMDR_DENSE_HI": "0"})
         o3, r3 = run(X, Q, n, d, B, k, steps, {"AMDR_DENSE_HI_TAIL": "0"})
         o4, r4 = run(X, Q, n, d, B, k, steps, {"AMDR_DENSE_HI_TAIL": "1"})

@@ -22,8 +22,23 @@ def main():
     ap.add_argument("csv")
     ap.add_argument("--pmc", action="store_true")
     ap.add_argument("--only", default="amdr::", help="substring filter on kernel names ('' = all)")
+    ap.add_argument("--timeline", type=int, default=0, help="print the last N dispatches in start order: start offset, "
+                    "duration, gap to the end of the previous dispatch (us)")
     a = ap.parse_args()
     rows = list(csv.DictReader(open(a.csv)))
+    if a.timeline:
+        seq = sorted((r for r in rows if a.only in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))[-a.timeline:]
+        t0 = int(seq[0]["Start_Timestamp"])
+        prev_end = None
+        print("| # | kernel | grid | start us | dur us | gap us |")
+        print("|---|---|---|---|---|---|")
+        for i, r in enumerate(seq):
+            st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            grid = r.get("Grid_Size") or "x".join(r[f"Grid_Size_{c}"] for c in "XYZ")
+            gap = "" if prev_end is None else f"{(st - prev_end) / 1e3:.1f}"
+            print(f"| {i} | `{short(r['Kernel_Name'])}` | {grid} | {(st - t0) / 1e3:.1f} | {(en - st) / 1e3:.1f} | {gap} |")
+            prev_end = en
+        return
     if a.pmc:
         agg = collections.defaultdict(list)
         for r in rows:

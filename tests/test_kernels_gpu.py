@@ -668,13 +668,18 @@ def test_maxsim_two_pass_topk_equals_one_pass(nat, monkeypatch):
 
     def run(D, doc_ptr, Q, k):
         out = {}
-        for flag in ("1", "0"):
-            monkeypatch.setenv("AMDR_MAXSIM_TWOPASS", flag)
+        # "1": two passes, the candidates re-scored by document (round 4: a block = one document x 8 of its queries);
+        # "1r3": two passes, one wave per candidate pair (round 3); "0": one pass
+        for flag, rescore in (("1", "1"), ("1r3", "0"), ("0", "1")):
+            monkeypatch.setenv("AMDR_MAXSIM_TWOPASS", flag[0])
+            monkeypatch.setenv("AMDR_MAXSIM_RESCORE", rescore)
             idx = nat.MaxSimIndex(D, doc_ptr)
             out[flag] = idx.search(Q, k)
             idx.close()
-        assert np.array_equal(out["1"][1], out["0"][1]), k
-        assert np.array_equal(out["1"][0], out["0"][0]), k
+        monkeypatch.delenv("AMDR_MAXSIM_RESCORE")
+        for other in ("0", "1r3"):
+            assert np.array_equal(out["1"][1], out[other][1]), (k, other)
+            assert np.array_equal(out["1"][0], out[other][0]), (k, other)
         return out["1"]
 
     for n_docs, nq, q_len, ks in ((591, 24, 32, (1, 10, 80)), (130, 9, 17, (5, 32)), (1300, 16, 32, (10,)), (50, 8, 32, (10, 13))):
