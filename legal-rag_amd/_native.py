@@ -33,7 +33,7 @@ EXPORTS = (
     "amdr_dense_plan_info", "amdr_dense_workspace_plan", "amdr_dense_hi_counters", "amdr_dense_profile_begin", "amdr_dense_profile_end", "amdr_dense_destroy",
     "amdr_bm25_create", "amdr_bm25_ndocs", "amdr_bm25_reserve", "amdr_bm25_search", "amdr_bm25_search_device",
     "amdr_bm25_scores", "amdr_bm25_destroy",
-    "amdr_tokenizer_create", "amdr_tokenizer_encode", "amdr_tokenizer_spans", "amdr_tokenizer_destroy",
+    "amdr_tokenizer_create", "amdr_tokenizer_encode", "amdr_tokenizer_encode_joined", "amdr_tokenizer_spans", "amdr_tokenizer_destroy",
     "amdr_maxsim_create", "amdr_maxsim_ndocs", "amdr_maxsim_plan_info", "amdr_maxsim_reserve", "amdr_maxsim_search",
     "amdr_maxsim_search_device", "amdr_maxsim_scores", "amdr_maxsim_destroy",
     "amdr_fuse", "amdr_fuse_device", "amdr_rerank_blend", "amdr_rerank_blend_device",
@@ -55,7 +55,7 @@ SIGNATURES = {
     "amdr_bm25_create": "PPPPPlldddiP", "amdr_bm25_ndocs": "PP", "amdr_bm25_reserve": "Piil",
     "amdr_bm25_search": "PPPiiPP", "amdr_bm25_search_device": "PPPiiPPP", "amdr_bm25_scores": "PPPiP",
     "amdr_bm25_destroy": "P",
-    "amdr_tokenizer_create": "PPlP", "amdr_tokenizer_encode": "PPPiPlPP", "amdr_tokenizer_spans": "PlPPiP",
+    "amdr_tokenizer_create": "PPlP", "amdr_tokenizer_encode": "PPPiPlPP", "amdr_tokenizer_encode_joined": "PPliPlPP", "amdr_tokenizer_spans": "PlPPiP",
     "amdr_tokenizer_destroy": "P",
     "amdr_maxsim_create": "PPliiP", "amdr_maxsim_ndocs": "PP", "amdr_maxsim_plan_info": "PiPi", "amdr_maxsim_reserve": "Pii",
     "amdr_maxsim_search": "PPiiiPP", "amdr_maxsim_search_device": "PPiiiPPP", "amdr_maxsim_scores": "PPiiP",
@@ -369,21 +369,32 @@ class Tokenizer:
 
     def encode(self, texts: Sequence[str]) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         """(term_ids i32 [total], q_ptr i64 [n+1], needs_segmenter bool [n]) — the CSR BM25Index.search takes.
-        Queries flagged needs_segmenter hold a Han character and got NO terms here."""
-        enc = [t.encode("utf-8") for t in texts]
-        blob = b"".join(enc)
-        n = len(enc)
-        offs = np.zeros(n + 1, dtype=np.int64)
-        if n:
-            np.cumsum([len(e) for e in enc], out=offs[1:])
+        Queries flagged needs_segmenter hold a Han character and got NO terms here.  The batch crosses into native code
+        as ONE blob: the queries joined by NUL bytes and encoded once (two C-level operations however long the batch);
+        a batch that itself contains a NUL takes the per-query offsets form."""
+        n = len(texts)
+        if n == 0:
+            return np.zeros(0, np.int32), np.zeros(1, np.int64), np.zeros(0, bool)
+        blob = "\0".join(texts).encode("utf-8")
         cap = max(len(blob), 1)
         terms = np.empty(cap, dtype=np.int32)
         q_ptr = np.zeros(n + 1, dtype=np.int64)
-        flags = np.zeros(max(n, 1), dtype=np.int32)
-        _check(load().amdr_tokenizer_encode(self._h, C.c_char_p(blob), _p(offs, C.c_int64), C.c_int32(n),
-                                            _p(terms, C.c_int32), C.c_int64(cap), _p(q_ptr, C.c_int64), _p(flags, C.c_int32)),
-               "amdr_tokenizer_encode")
-        return terms[: int(q_ptr[-1])], q_ptr, flags[:n].astype(bool)
+        flags = np.zeros(n, dtype=np.int32)
+        if blob.count(b"\0") == n - 1:
+            _check(load().amdr_tokenizer_encode_joined(self._h, blob, len(blob), n, _p(terms, C.c_int32), cap,
+                                                       _p(q_ptr, C.c_int64), _p(flags, C.c_int32)),
+                   "amdr_tokenizer_encode_joined")
+        else:
+            enc = [t.encode("utf-8") for t in texts]
+            blob = b"".join(enc)
+            offs = np.zeros(n + 1, dtype=np.int64)
+            np.cumsum([len(e) for e in enc], out=offs[1:])
+            cap = max(len(blob), 1)
+            terms = np.empty(cap, dtype=np.int32)
+            _check(load().amdr_tokenizer_encode(self._h, C.c_char_p(blob), _p(offs, C.c_int64), C.c_int32(n),
+                                                _p(terms, C.c_int32), C.c_int64(cap), _p(q_ptr, C.c_int64), _p(flags, C.c_int32)),
+                   "amdr_tokenizer_encode")
+        return terms[: int(q_ptr[-1])], q_ptr, flags.astype(bool)
 
     @staticmethod
     def cut(text: str) -> Optional[list]:

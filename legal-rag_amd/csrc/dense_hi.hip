@@ -539,8 +539,11 @@ static int launch_hi_d(const float* X, long n, int d, const float* Q, int nq, fl
   AMDR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   const long tiles = (n + 31) / 32;
   const long n_items = (tiles + tile_stride - 1) / tile_stride;
-  long blocks = (n_items + kHiWaves - 1) / kHiWaves;
-  if (blocks > cus) blocks = cus;
+  // the full scan: one persistent block per CU.  The sample (grid_y query tiles in one launch): its items spread over ALL
+  // CUs — cus / grid_y blocks per tile, a wave gets one item or none — rather than 8 per block on fewer CUs: it is bound
+  // by the bytes its CUs can pull
+  long blocks = EMIT ? (n_items + kHiWaves - 1) / kHiWaves : n_items;
+  if (blocks > cus / grid_y) blocks = cus / grid_y;
   if (blocks < 1) blocks = 1;
   const int grid = (int)blocks;
   switch (d / 64) {
@@ -660,6 +663,10 @@ __global__ __launch_bounds__(64) void dense_hi_tau_kernel(const float* __restric
     const int i = lane + 64 * v;
     key[v] = i < items ? ord32(row[i]) : 0u;
   }
+  // pin the keys in registers: hipcc otherwise re-LOADS them from the (const, restrict) row in every one of the 32
+  // rounds below instead of holding 32 registers (the kernel reported 20 VGPRs and took 24 us)
+#pragma unroll
+  for (int v = 0; v < 32; ++v) asm volatile("" : "+v"(key[v]));
   u32 K = 0u;
 #pragma unroll 1
   for (int bit = 31; bit >= 0; --bit) {
@@ -859,7 +866,13 @@ __global__ __launch_bounds__(256) void dense_hi_exact_select_kernel(const float*
 // tiles in ONE launch)
 long dense_hi2_sample_stride(long n, int qtiles) {
   const long tiles = (n + 31) / 32;
-  long per = 2048 / (qtiles < 1 ? 1 : qtiles);
+  // The sample READS its tiles (96 KiB each at d = 768: 2 048 tiles = 197 MB, 30-47 us — bandwidth, not latency), and a
+  // coarser sample only loosens the threshold: kc x stride entries per query reach the lists.  About every 32nd tile, at
+  // least 512 and at most 2 048 tiles in all: a 1.25 M-row shard samples 1 221 tiles (~1 050 entries per query at k = 10:
+  // the register selector's range), 10 M rows 2 048.
+  long total = tiles / 32;
+  total = total < 512 ? 512 : (total > 2048 ? 2048 : total);
+  long per = total / (qtiles < 1 ? 1 : qtiles);
   per = per / kHiWaves * kHiWaves;
   if (per < kHiWaves) per = kHiWaves;
   const long s = (tiles + per - 1) / per;

@@ -636,7 +636,7 @@ int dense_tiles_remap_launch(int64_t* ids, int total, const int* list, const int
 // columns, and only the two row blocks are multiplied: 16 MFMAs per chunk instead of 32, the k-steps in the SAME order —
 // acc[bj] sees the sequence the tile kernel's acc[bi][bj] sees, hence the same bits (tested against modes 0 / 2 / 3).
 // 20 KiB of LDS per 4-wave block: the candidate tiles of a batch spread over every CU.
-// grid: (ceil(max tiles per query / WPB), queries).
+// grid: (queries, ceil(max tiles per query / WPB)).
 template <int D8, int WPB>
 __global__ __launch_bounds__(WPB * 64) void dense_rescore_tiles_kernel(const float* __restrict__ X, long n_real,
                                                                        const float* __restrict__ Q,
@@ -650,13 +650,16 @@ __global__ __launch_bounds__(WPB * 64) void dense_rescore_tiles_kernel(const flo
   // was bound by the latency of its own loads (64 queries: 27 us for 86 MB)
   constexpr int kRsDepth = 8;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int q = blockIdx.y;
+  // grid (queries, tile groups): the blocks that hold the HEADS of the lists — the live ones — are dispatched first and
+  // land one per CU; with the tile group as the fast index the 4 live blocks of a query sat next to 5 dead ones and the
+  // live blocks clumped on the CUs the dead ones had just freed (27 us for 86 MB)
+  const int q = blockIdx.x;
   const int cnt = count[q];
-  if ((int)blockIdx.x * WPB >= cnt) return;  // block-uniform: nothing of this query's list falls to the block
+  if ((int)blockIdx.y * WPB >= cnt) return;  // block-uniform: nothing of this query's list falls to the block
   v4f* qv = reinterpret_cast<v4f*>(smem);
   for (int i = threadIdx.x; i < d / 4; i += WPB * 64) qv[i] = *reinterpret_cast<const v4f*>(Q + (size_t)q * d + 4 * i);
   __syncthreads();
-  const int t = blockIdx.x * WPB + wave;
+  const int t = blockIdx.y * WPB + wave;
   if (t >= cnt) return;
   unsigned char* stage = smem + (size_t)d * 4 + (size_t)wave * kStageBytes;
   const int i16 = lane & 15, kq = lane >> 4;
@@ -922,7 +925,7 @@ static int launch_rescore(const float* X, long n_real, const float* Q, int m, co
                           int list_stride, int max_tiles, long ldS, float* S, hipStream_t st) {
   constexpr int WPB = 4;
   const size_t lds = (size_t)D8 * 8 * sizeof(float) + (size_t)WPB * kStageBytes;
-  hipLaunchKernelGGL((dense_rescore_tiles_kernel<D8, WPB>), dim3((max_tiles + WPB - 1) / WPB, m), dim3(WPB * 64), lds, st, X,
+  hipLaunchKernelGGL((dense_rescore_tiles_kernel<D8, WPB>), dim3(m, (max_tiles + WPB - 1) / WPB), dim3(WPB * 64), lds, st, X,
                      n_real, Q, list, count, list_stride, ldS, S);
   return AMDR_OK;
 }

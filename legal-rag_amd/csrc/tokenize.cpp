@@ -15,17 +15,46 @@
 // caller takes the Python path (which raises unless a segmenter or the explicit stand-in is configured).
 // Queries are NOT lower-cased (the reference does not, bm25_retriever.py:73).  One call handles a whole batch and
 // writes the term-id CSR amdr_bm25_search takes; ctypes releases the GIL for its duration.
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <new>
+#include <pthread.h>
 #include <string>
-#include <unordered_map>
+#include <thread>
 #include <vector>
 
 #include "common.hpp"
 
+// The vocabulary as an open-addressing table over ONE copy of the term bytes: a lookup hashes the token's bytes where
+// they lie in the query (no std::string is built per token) and compares with memcmp.
 struct amdr_tokenizer {
-  std::unordered_map<std::string, int32_t> vocab;
+  std::string blob;               // all terms, back to back
+  std::vector<int64_t> offs;      // term i = blob[offs[i] .. offs[i + 1])
+  std::vector<int32_t> slots;     // -1 = empty, else a term id; size = power of two >= 2 x terms
+  uint32_t mask = 0;
+  int32_t single[256];            // one-byte tokens (blanks and punctuation are two thirds of a query's tokens): direct
+  static inline uint32_t hash(const unsigned char* p, size_t n) {  // FNV-1a, folded
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; ++i) h = (h ^ p[i]) * 1099511628211ull;
+    return (uint32_t)(h ^ (h >> 32));
+  }
+  inline int32_t find(const unsigned char* p, size_t n) const {
+    if (n == 1) return single[p[0]];
+    return find_slow(p, n);
+  }
+  inline int32_t find_slow(const unsigned char* p, size_t n) const {
+    if (slots.empty()) return -1;
+    for (uint32_t i = hash(p, n) & mask;; i = (i + 1) & mask) {
+      const int32_t id = slots[i];
+      if (id < 0) return -1;
+      const int64_t lo = offs[id];
+      if ((size_t)(offs[id + 1] - lo) == n && memcmp(blob.data() + lo, p, n) == 0) return id;
+    }
+  }
 };
 
 namespace {
@@ -125,9 +154,39 @@ inline void cut_block(const unsigned char* s, int lo, int hi, Emit&& emit) {
   flush(buf, hi);
 }
 
+// byte classes of the ASCII fast path: 1 = block character ([a-zA-Z0-9+#&._%-]), 0 = anything else
+struct AsciiBlock {
+  unsigned char t[256];
+  AsciiBlock() {
+    for (int c = 0; c < 256; ++c) t[c] = (c < 0x80 && is_block((uint32_t)c)) ? 1 : 0;
+  }
+};
+static const AsciiBlock kAsciiBlock;
+
 // tokens of one sentence; returns false (nothing emitted is meaningful) when it holds a Han character
 template <class Emit>
 inline bool tokenize(const unsigned char* s, int n, Emit&& emit) {
+  // pure ASCII (every English query): no decoding, no Han check, one table lookup per byte — the same rule
+  bool ascii = true;
+  for (int i = 0; i < n; ++i) ascii &= s[i] < 0x80;
+  if (ascii) {
+    int i = 0;
+    while (i < n) {
+      if (kAsciiBlock.t[s[i]]) {
+        int j = i + 1;
+        while (j < n && kAsciiBlock.t[s[j]]) ++j;
+        cut_block(s, i, j, emit);
+        i = j;
+      } else if (s[i] == '\r' && i + 1 < n && s[i + 1] == '\n') {
+        emit(i, i + 2);
+        i += 2;
+      } else {
+        emit(i, i + 1);
+        ++i;
+      }
+    }
+    return true;
+  }
   const unsigned char* end = s + n;
   for (int i = 0; i < n;) {  // Han anywhere -> the whole sentence goes to the caller's segmenter
     int len;
@@ -166,52 +225,215 @@ int amdr_tokenizer_create(const char* vocab_blob, const int64_t* vocab_offsets, 
                           amdr_tokenizer_t** out) {
   AMDR_REQUIRE(out != nullptr, "tokenizer_create: out is null");
   *out = nullptr;
-  AMDR_REQUIRE(n_terms >= 0 && n_terms < (1ll << 31) && (n_terms == 0 || (vocab_blob && vocab_offsets)),
+  AMDR_REQUIRE(n_terms >= 0 && n_terms < (1ll << 30) && (n_terms == 0 || (vocab_blob && vocab_offsets)),
                "tokenizer_create: bad vocabulary");
   amdr_tokenizer* t = new (std::nothrow) amdr_tokenizer();
   if (!t) return amdr::fail(AMDR_ENOMEM, "tokenizer_create: host alloc");
-  t->vocab.reserve((size_t)n_terms * 2);
+  for (int c = 0; c < 256; ++c) t->single[c] = -1;
   for (int64_t i = 0; i < n_terms; ++i) {
-    const int64_t lo = vocab_offsets[i], hi = vocab_offsets[i + 1];
-    if (hi < lo) {
+    if (vocab_offsets[i + 1] < vocab_offsets[i]) {
       delete t;
       return amdr::fail(AMDR_EINVAL, "tokenizer_create: offsets not ascending at term %lld", (long long)i);
     }
-    t->vocab.emplace(std::string(vocab_blob + lo, (size_t)(hi - lo)), (int32_t)i);  // first id of a repeated term wins
+  }
+  if (n_terms) {
+    const int64_t base = vocab_offsets[0];
+    t->blob.assign(vocab_blob + base, (size_t)(vocab_offsets[n_terms] - base));
+    t->offs.resize((size_t)n_terms + 1);
+    for (int64_t i = 0; i <= n_terms; ++i) t->offs[(size_t)i] = vocab_offsets[i] - base;
+    size_t cap = 16;
+    while (cap < (size_t)n_terms * 2) cap <<= 1;
+    t->slots.assign(cap, -1);
+    t->mask = (uint32_t)(cap - 1);
+    for (int64_t i = 0; i < n_terms; ++i) {  // first id of a repeated term wins
+      const unsigned char* p = reinterpret_cast<const unsigned char*>(t->blob.data()) + t->offs[(size_t)i];
+      const size_t n = (size_t)(t->offs[(size_t)i + 1] - t->offs[(size_t)i]);
+      if (t->find_slow(p, n) >= 0) continue;
+      uint32_t j = amdr_tokenizer::hash(p, n) & t->mask;
+      while (t->slots[j] >= 0) j = (j + 1) & t->mask;
+      t->slots[j] = (int32_t)i;
+      if (n == 1) t->single[p[0]] = (int32_t)i;
+    }
   }
   *out = t;
   return AMDR_OK;
 }
+
+}  // extern "C"
+
+namespace {
+
+// A small persistent pool: a batch of tens of thousands of queries is cut into ranges, one per worker; starting
+// std::threads per call cost more than tokenising a few thousand queries.  Workers sleep on a condition variable
+// between calls; calls from several Python threads are serialised on the pool (each still runs on all workers).
+class Pool {
+ public:
+  static Pool& get() {
+    // never destroyed: no join at process exit (detached daemon threads).  A forked child has none of the parent's
+    // threads: it starts its own pool at its first batch.
+    static std::once_flag once;
+    std::call_once(once, [] { pthread_atfork(nullptr, nullptr, [] { inst().store(nullptr); }); });
+    Pool* p = inst().load();
+    if (!p) {
+      static std::mutex mk;
+      std::lock_guard<std::mutex> g(mk);
+      p = inst().load();
+      if (!p) {
+        p = new Pool();
+        inst().store(p);
+      }
+    }
+    return *p;
+  }
+  static std::atomic<Pool*>& inst() {
+    static std::atomic<Pool*> i{nullptr};
+    return i;
+  }
+  int workers() const { return (int)th_.size() + 1; }
+  // fn(part) for part = 0 .. parts - 1, parts <= workers(); the caller runs part 0
+  void run(int parts, const std::function<void(int)>& fn) {
+    if (parts <= 1) {
+      fn(0);
+      return;
+    }
+    std::lock_guard<std::mutex> call(call_mu_);
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      fn_ = &fn;
+      parts_ = parts;
+      pending_ = parts - 1;
+      ++gen_;
+    }
+    cv_.notify_all();
+    fn(0);
+    std::unique_lock<std::mutex> g(mu_);
+    done_.wait(g, [&] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  Pool() {
+    int n = (int)std::thread::hardware_concurrency();
+    const char* e = getenv("AMDR_TOKENIZER_THREADS");
+    if (e && atoi(e) >= 1) n = atoi(e);
+    if (n > 16) n = 16;
+    if (n < 1) n = 1;
+    for (int i = 1; i < n; ++i) {
+      th_.emplace_back([this, i] { loop(i); });
+      th_.back().detach();
+    }
+  }
+  void loop(int id) {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(int)>* fn = nullptr;
+      {
+        std::unique_lock<std::mutex> g(mu_);
+        cv_.wait(g, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (id < parts_) fn = fn_;
+      }
+      if (fn) {
+        (*fn)(id);
+        std::lock_guard<std::mutex> g(mu_);
+        if (--pending_ == 0) done_.notify_one();
+      }
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex mu_, call_mu_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int)>* fn_ = nullptr;
+  int parts_ = 0, pending_ = 0;
+  uint64_t gen_ = 0;
+};
+
+// the batch core: queries text[offs[q] .. offs[q + 1] - trim) -> CSR.  Two phases: every worker tokenises its range of
+// queries into its own term buffer (+ per-query counts), then the prefix sum over the counts gives q_ptr and every
+// worker copies its terms to their place.
+int encode_core(const amdr_tokenizer* t, const unsigned char* text, const int64_t* offs, int64_t trim, int32_t nq,
+                int32_t* term_ids, int64_t capacity, int64_t* q_ptr, int32_t* needs_segmenter) {
+  if (nq == 0) return AMDR_OK;
+  q_ptr[0] = 0;
+  Pool& pool = Pool::get();
+  int parts = pool.workers();
+  if (parts > nq / 256) parts = nq / 256;  // a worker is worth waking for a few hundred queries
+  if (parts < 1) parts = 1;
+  std::vector<std::vector<int32_t>> bufs((size_t)parts);
+  std::atomic<int> bad{-1};
+  auto range = [&](int p, int32_t* lo, int32_t* hi) {
+    *lo = (int32_t)((int64_t)nq * p / parts);
+    *hi = (int32_t)((int64_t)nq * (p + 1) / parts);
+  };
+  std::function<void(int)> phase1 = [&](int p) {
+    int32_t lo, hi;
+    range(p, &lo, &hi);
+    std::vector<int32_t>& out = bufs[(size_t)p];
+    out.reserve((size_t)((offs[hi] - offs[lo]) / 2 + 16));
+    for (int32_t q = lo; q < hi; ++q) {
+      const int64_t a = offs[q], b = offs[q + 1] - (q + 1 < nq ? trim : 0);
+      if (b < a || b - a >= (1ll << 31)) {
+        bad.store(q);
+        return;
+      }
+      const unsigned char* s = text + a;
+      const size_t start = out.size();
+      const bool ok = tokenize(s, (int)(b - a), [&](int x, int y) { out.push_back(t->find(s + x, (size_t)(y - x))); });
+      if (!ok) out.resize(start);
+      needs_segmenter[q] = ok ? 0 : 1;
+      q_ptr[q + 1] = (int64_t)(out.size() - start);  // the count; turned into the offset below
+    }
+  };
+  pool.run(parts, phase1);
+  AMDR_REQUIRE(bad.load() < 0, "tokenizer_encode: bad offsets at query %d", bad.load());
+  for (int32_t q = 0; q < nq; ++q) q_ptr[q + 1] += q_ptr[q];
+  AMDR_REQUIRE(q_ptr[nq] <= capacity, "tokenizer_encode: term buffer too small (capacity %lld, %lld terms)",
+               (long long)capacity, (long long)q_ptr[nq]);
+  std::function<void(int)> phase2 = [&](int p) {
+    int32_t lo, hi;
+    range(p, &lo, &hi);
+    const std::vector<int32_t>& src = bufs[(size_t)p];
+    if (!src.empty()) memcpy(term_ids + q_ptr[lo], src.data(), src.size() * sizeof(int32_t));
+  };
+  pool.run(parts, phase2);
+  return AMDR_OK;
+}
+
+}  // namespace
+
+extern "C" {
 
 int amdr_tokenizer_encode(const amdr_tokenizer_t* t, const char* text_blob, const int64_t* text_offsets, int32_t nq,
                           int32_t* term_ids, int64_t capacity, int64_t* q_ptr, int32_t* needs_segmenter) {
   AMDR_REQUIRE(t != nullptr, "tokenizer_encode: null handle");
   AMDR_REQUIRE(nq >= 0 && (nq == 0 || (text_offsets && q_ptr && needs_segmenter)), "tokenizer_encode: null buffer");
   AMDR_REQUIRE(capacity >= 0 && (capacity == 0 || term_ids), "tokenizer_encode: null term buffer");
-  int64_t at = 0;
-  std::string key;
-  if (nq) q_ptr[0] = 0;
-  for (int32_t q = 0; q < nq; ++q) {
-    const int64_t lo = text_offsets[q], hi = text_offsets[q + 1];
-    AMDR_REQUIRE(hi >= lo && hi - lo < (1ll << 31), "tokenizer_encode: bad offsets at query %d", q);
-    const unsigned char* s = reinterpret_cast<const unsigned char*>(text_blob) + lo;
-    const int64_t start = at;
-    bool overflow = false;
-    const bool ok = tokenize(s, (int)(hi - lo), [&](int a, int b) {
-      if (at >= capacity) {
-        overflow = true;
-        return;
-      }
-      key.assign(reinterpret_cast<const char*>(s) + a, (size_t)(b - a));
-      auto it = t->vocab.find(key);
-      term_ids[at++] = it == t->vocab.end() ? -1 : it->second;
-    });
-    AMDR_REQUIRE(!overflow, "tokenizer_encode: term buffer too small (capacity %lld)", (long long)capacity);
-    if (!ok) at = start;
-    needs_segmenter[q] = ok ? 0 : 1;
-    q_ptr[q + 1] = at;
+  return encode_core(t, reinterpret_cast<const unsigned char*>(text_blob), text_offsets, 0, nq, term_ids, capacity, q_ptr,
+                     needs_segmenter);
+}
+
+int amdr_tokenizer_encode_joined(const amdr_tokenizer_t* t, const char* text_blob, int64_t n_bytes, int32_t nq,
+                                 int32_t* term_ids, int64_t capacity, int64_t* q_ptr, int32_t* needs_segmenter) {
+  AMDR_REQUIRE(t != nullptr, "tokenizer_encode_joined: null handle");
+  AMDR_REQUIRE(nq >= 0 && n_bytes >= 0 && (nq == 0 || (q_ptr && needs_segmenter)), "tokenizer_encode_joined: null buffer");
+  AMDR_REQUIRE(n_bytes == 0 || text_blob, "tokenizer_encode_joined: null text");
+  AMDR_REQUIRE(capacity >= 0 && (capacity == 0 || term_ids), "tokenizer_encode_joined: null term buffer");
+  if (nq == 0) return AMDR_OK;
+  // queries are separated by ONE NUL byte (nq - 1 of them): offsets from a memchr walk
+  std::vector<int64_t> offs((size_t)nq + 1);
+  offs[0] = 0;
+  const char* p = text_blob;
+  const char* end = text_blob + n_bytes;
+  for (int32_t q = 1; q < nq; ++q) {
+    const char* z = p < end ? static_cast<const char*>(memchr(p, 0, (size_t)(end - p))) : nullptr;
+    AMDR_REQUIRE(z != nullptr, "tokenizer_encode_joined: %d queries announced, separator %d missing", nq, q);
+    offs[(size_t)q] = (z - text_blob) + 1;
+    p = z + 1;
   }
-  return AMDR_OK;
+  AMDR_REQUIRE(p > end || memchr(p, 0, (size_t)(end - p)) == nullptr, "tokenizer_encode_joined: more separators than queries");
+  offs[(size_t)nq] = n_bytes;
+  return encode_core(t, reinterpret_cast<const unsigned char*>(text_blob), offs.data(), 1, nq, term_ids, capacity, q_ptr,
+                     needs_segmenter);
 }
 
 int amdr_tokenizer_spans(const char* text, int64_t n_bytes, int32_t* starts, int32_t* ends, int32_t capacity,
