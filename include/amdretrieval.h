@@ -259,6 +259,14 @@ int amdr_rerank_blend_device(int32_t nq, int32_t max_out, const int32_t* count, 
                              int32_t* mask, const double* ce_raw, int32_t top_n, double beta,
                              double* out_rerank, int32_t device, void* stream);
 
+/* The columns a bulk caller reads from a fused result, compacted on the device: the first w fused hits of every query
+ * as out_rows / out_scores / out_mask [nq, w] (entries past min(count[q], w): -1 / 0.0 / 0) and out_count [nq] =
+ * min(count[q], w).  Inputs: the outputs of amdr_fuse_device (after the optional rerank blend).  One small device-to-host
+ * copy then serves HybridRetriever.search_batch_arrays (hybrid_retriever.py:309-310 + :384, the cut to top_k). */
+int amdr_fuse_compact_device(int32_t nq, int32_t max_out, int32_t w, const int64_t* ids, const double* vals,
+                             const int32_t* mask, const int32_t* count, int64_t* out_rows, double* out_scores,
+                             int32_t* out_mask, int32_t* out_count, int32_t device, void* stream);
+
 /* ---- multi-GPU: merge per-shard top-k after the RCCL all-gather --------
  * No reference counterpart (the reference is single-process).
  * parts: [n_parts, nq, k_in] scores + GLOBAL ids (-1 padding); output

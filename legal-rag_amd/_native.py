@@ -36,7 +36,7 @@ EXPORTS = (
     "amdr_tokenizer_create", "amdr_tokenizer_encode", "amdr_tokenizer_encode_joined", "amdr_tokenizer_spans", "amdr_tokenizer_destroy",
     "amdr_maxsim_create", "amdr_maxsim_ndocs", "amdr_maxsim_plan_info", "amdr_maxsim_reserve", "amdr_maxsim_search",
     "amdr_maxsim_search_device", "amdr_maxsim_scores", "amdr_maxsim_destroy",
-    "amdr_fuse", "amdr_fuse_device", "amdr_rerank_blend", "amdr_rerank_blend_device",
+    "amdr_fuse", "amdr_fuse_device", "amdr_rerank_blend", "amdr_rerank_blend_device", "amdr_fuse_compact_device",
     "amdr_merge_topk_f32_device", "amdr_merge_topk_f64_device",
     "amdr_shard_row_words", "amdr_shard_pack_device", "amdr_shard_merge_device",
 )
@@ -62,6 +62,7 @@ SIGNATURES = {
     "amdr_maxsim_destroy": "P",
     "amdr_fuse": "Pi" + "PPi" * 3 + "PPPP", "amdr_fuse_device": "Pi" + "PPiP" * 3 + "PPPP" + "iP",
     "amdr_rerank_blend": "iiPPPPPidP", "amdr_rerank_blend_device": "iiPPPPPidPiP",
+    "amdr_fuse_compact_device": "iiiPPPPPPPPiP",
     "amdr_merge_topk_f32_device": "PPiiiiPPiP", "amdr_merge_topk_f64_device": "PPiiiiPPiP",
     "amdr_shard_row_words": "PiP", "amdr_shard_pack_device": "PiilPiP", "amdr_shard_merge_device": "PiiPiiP",
 }
@@ -566,6 +567,12 @@ def rerank_blend_device(nq: int, max_out: int, count: int, ids: int, vals: int, 
                                            _vp(mask), _vp(ce_raw), C.c_int32(top_n), C.c_double(beta),
                                            _vp(out_rerank), C.c_int32(device), _vp(stream)),
            "amdr_rerank_blend_device")
+
+
+def fuse_compact_device(nq: int, max_out: int, w: int, ids: int, vals: int, mask: int, count: int, out_rows: int,
+                        out_scores: int, out_mask: int, out_count: int, *, device: int = 0, stream: int = 0) -> None:
+    _check(load().amdr_fuse_compact_device(nq, max_out, w, ids, vals, mask, count, out_rows, out_scores, out_mask, out_count,
+                                           device, stream), "amdr_fuse_compact_device")
 
 
 def merge_topk_device(scores: int, ids: int, n_parts: int, nq: int, k_in: int, k_out: int, out_scores: int,

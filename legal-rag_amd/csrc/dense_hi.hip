@@ -670,11 +670,12 @@ __global__ __launch_bounds__(64) void dense_hi_tau_kernel(const float* __restric
   u32 K = 0u;
 #pragma unroll 1
   for (int bit = 31; bit >= 0; --bit) {
+    // keys >= cand, counted on the scalar unit: 32 independent compares whose lane masks are popcounted and added as
+    // scalars (per-lane counts + a cross-lane sum were a dependent chain of ~110 vector instructions per bit: 13 us)
     const u32 cand = K | (1u << bit);
     int cnt = 0;
 #pragma unroll
-    for (int v = 0; v < 32; ++v) cnt += key[v] >= cand ? 1 : 0;
-    cnt = wave_allsum_i32(cnt);
+    for (int v = 0; v < 32; ++v) cnt += __popcll(__ballot(key[v] >= cand));
     if (cnt >= kc) K = cand;
   }
   if (lane == 0) {
@@ -874,7 +875,7 @@ long dense_hi2_sample_stride(long n, int qtiles) {
   total = total < 512 ? 512 : (total > 2048 ? 2048 : total);
   long per = total / (qtiles < 1 ? 1 : qtiles);
   per = per / kHiWaves * kHiWaves;
-  if (per < kHiWaves) per = kHiWaves;
+  if (per < 512) per = 512;  // per query tile: well above the widest cut (kc <= 256), or the kc-th sampled maximum does not exist
   const long s = (tiles + per - 1) / per;
   return s < 1 ? 1 : s;
 }

@@ -752,6 +752,30 @@ std::vector<char>& host_block() {
 }
 }  // namespace
 
+namespace amdr {
+// The columns a bulk caller reads, compacted on the device so that ONE small copy serves the host API: the first `w`
+// fused hits of every query as rows / scores / channel masks (entries past min(count, w): -1 / 0 / 0) + the clipped
+// counts.  The full fused record is 9 doubles per candidate and channel-depth x channels candidates per query — 1.6 KB
+// per query at top-10 of two channels; PCIe, not the kernels, then bounds a bulk search (hybrid_retriever
+// search_batch_arrays: 15 MB per 9 344 queries).  Here: 20 bytes per kept hit.
+__global__ __launch_bounds__(256) void fuse_compact_kernel(const long long* __restrict__ ids, const double* __restrict__ vals,
+                                                           const int* __restrict__ mask, const int* __restrict__ count,
+                                                           int nq, int max_out, int w, long long* __restrict__ out_rows,
+                                                           double* __restrict__ out_scores, int* __restrict__ out_mask,
+                                                           int* __restrict__ out_count) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)nq * w) return;
+  const int q = (int)(i / w), j = (int)(i - (long)q * w);
+  const int c = count[q] < w ? count[q] : w;
+  const bool keep = j < c;
+  const size_t src = (size_t)q * max_out + j;
+  out_rows[i] = keep ? ids[src] : -1ll;
+  out_scores[i] = keep ? vals[src * AMDR_FUSE_NVALS + AMDR_FV_SCORE] : 0.0;
+  out_mask[i] = keep ? mask[src] : 0;
+  if (j == 0) out_count[q] = c;
+}
+}  // namespace amdr
+
 extern "C" {
 
 int amdr_fuse_device(const amdr_fuse_params_t* p, int32_t nq, const int64_t* dense_ids, const float* dense_scores,
@@ -788,6 +812,21 @@ int amdr_rerank_blend_device(int32_t nq, int32_t max_out, const int32_t* count, 
     AMDR_HIP(hipFuncSetAttribute((const void*)rerank_blend_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(rerank_blend_kernel, dim3(nq), dim3(64), lds, (hipStream_t)stream, max_out, count,
                      (long long*)ids, vals, mask, ce_raw, top_n, beta, out_rerank);
+  AMDR_HIP(hipGetLastError());
+  return AMDR_OK;
+}
+
+int amdr_fuse_compact_device(int32_t nq, int32_t max_out, int32_t w, const int64_t* ids, const double* vals,
+                             const int32_t* mask, const int32_t* count, int64_t* out_rows, double* out_scores,
+                             int32_t* out_mask, int32_t* out_count, int32_t device, void* stream) {
+  AMDR_REQUIRE(nq >= 0 && max_out >= 1 && w >= 1 && w <= max_out, "fuse_compact: bad sizes (max_out=%d w=%d)", max_out, w);
+  if (nq == 0) return AMDR_OK;
+  AMDR_REQUIRE(ids && vals && mask && count && out_rows && out_scores && out_mask && out_count, "fuse_compact: null buffer");
+  AMDR_HIP(hipSetDevice(device));
+  const long total = (long)nq * w;
+  hipLaunchKernelGGL(amdr::fuse_compact_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const long long*)ids, vals, mask, count, nq, max_out, w, (long long*)out_rows, out_scores, out_mask,
+                     out_count);
   AMDR_HIP(hipGetLastError());
   return AMDR_OK;
 }

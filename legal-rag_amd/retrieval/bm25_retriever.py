@@ -94,13 +94,23 @@ class BM25Retriever:
         from .. import _native
         self.load()
         n = len(questions)
-        native_ok = text._custom_cut is None and not text.HAVE_JIEBA
+        # A registered segmenter sees every query.  With jieba installed — every real deployment of the reference — text
+        # without Han characters still takes the native tokeniser (jieba decides it without its dictionary, text.py),
+        # EXCEPT a query that holds one of the ASCII entries of jieba's dictionary (text._ASCII_DICT_WORDS: the one place
+        # where the dictionary reaches into ASCII text): that query, like a Han one, goes to jieba itself.  The fallback is
+        # per query, not per process (round 3 sent every English query through per-query Python once jieba was importable).
+        native_ok = text._custom_cut is None
         if native_ok:
             tok = self.__dict__.get("_native_tok")
             if tok is None or tok[0] is not self.bm25:
                 tok = (self.bm25, _native.Tokenizer(list(self.bm25.vocab().keys())))
                 self.__dict__["_native_tok"] = tok
-            terms, q_ptr, hard = tok[1].encode([q or "" for q in questions])
+            qs = [q or "" for q in questions]
+            terms, q_ptr, hard = tok[1].encode(qs)
+            if text.HAVE_JIEBA:
+                joined = "\0".join(qs)
+                if any(w in joined for w in text._ASCII_DICT_WORDS):  # rare: find the queries concerned
+                    hard = hard | np.fromiter((any(w in q for w in text._ASCII_DICT_WORDS) for q in qs), dtype=bool, count=n)
             exact = np.full(n, self.index_tokenizer != "char", dtype=bool)
             if not hard.any():
                 return terms, q_ptr, exact

@@ -80,6 +80,54 @@ class HybridEngine:
             self._bufs[key] = t
         return t
 
+    def _pinned(self, name, nbytes: int):
+        """A page-locked host buffer of at least nbytes (grown geometrically, reused): staging for the one H2D copy of a
+        batch's BM25 query CSR and the one D2H copy of its results — copies from / to pageable memory go through the
+        driver's own bounce buffer synchronously."""
+        key = ("pin", name)
+        t = self._bufs.get(key)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty((max(int(nbytes), 2 * (t.numel() if t is not None else 0), 4096),), dtype=torch.uint8).pin_memory()
+            self._bufs[key] = t
+        return t
+
+    def upload_csr(self, q_ptr, q_terms):
+        """BM25 query CSR (numpy int64 [n+1], int32 [total]) -> device tensors through ONE pinned staging copy."""
+        import numpy as np
+        qp8, qt8 = q_ptr.view(np.uint8), q_terms.view(np.uint8)
+        n1, n2 = qp8.size, qt8.size
+        host = self._pinned("csr", n1 + n2)
+        hv = host.numpy()
+        hv[:n1] = qp8
+        hv[n1:n1 + n2] = qt8
+        dev = self._bufs.get(("csr_dev",))
+        if dev is None or dev.numel() < n1 + n2:
+            dev = torch.empty((host.numel(),), dtype=torch.uint8, device=self.tdev)
+            self._bufs[("csr_dev",)] = dev
+        dev[: n1 + n2].copy_(host[: n1 + n2], non_blocking=True)
+        return dev[:n1].view(torch.int64), dev[n1:n1 + n2].view(torch.int32)
+
+    def compact_to_host(self, res: "BatchResult", w: int):
+        """(rows i64 [nq, w], scores f64 [nq, w], channel mask i32 [nq, w], count i32 [nq]) of a fused result on the host:
+        compacted by ONE kernel (amdr_fuse_compact_device), ONE copy into pinned memory, one synchronise."""
+        nq, mo = res.ids.shape
+        w = max(1, min(int(w), int(mo)))
+        o1 = nq * w * 8
+        o2 = o1 + nq * w * 8
+        o3 = o2 + nq * w * 4
+        tot = o3 + nq * 4
+        pk = self._buf("cpk", (tot,), torch.uint8)
+        base = pk.data_ptr()
+        _native.fuse_compact_device(nq, mo, w, res.ids.data_ptr(), res.vals.data_ptr(), res.mask.data_ptr(),
+                                    res.count.data_ptr(), base, base + o1, base + o2, base + o3, device=self.device,
+                                    stream=_stream())
+        host = self._pinned("cpkh", tot)
+        host[:tot].copy_(pk, non_blocking=True)
+        torch.cuda.current_stream(self.tdev).synchronize()
+        h = host.numpy()
+        return (h[:o1].view("int64").reshape(nq, w).copy(), h[o1:o2].view("float64").reshape(nq, w).copy(),
+                h[o2:o3].view("int32").reshape(nq, w).copy(), h[o3:tot].view("int32").copy())
+
     def reserve(self, nq: int, k: int, total_terms: int = 0) -> None:
         if self.dense is not None:
             self.dense.reserve(nq, k)

@@ -425,6 +425,16 @@ def test_search_batch_arrays_equals_search_batch(ucc_index):
             assert col["values"][q, j, col["value_names"]["rrf_norm"]] == h.score_breakdown["rrf_norm"]
     with pytest.raises(ValueError):
         r.search_batch_arrays(["ok", "  "], top_k=5)
+    # values=False: the lean columnar form, compacted on the device (amdr_fuse_compact_device) — the same rows / scores /
+    # masks / counts as the full form's first top_k columns
+    for k in (3, 10, 50):
+        full = r.search_batch_arrays(QUESTIONS * 5, top_k=k)
+        lean = r.search_batch_arrays(QUESTIONS * 5, top_k=k, values=False)
+        w = lean["rows"].shape[1]
+        assert "values" not in lean and w == min(k, full["rows"].shape[1])
+        for key in ("rows", "scores", "channel_mask"):
+            assert np.array_equal(lean[key], full[key][:, :w]), (k, key)
+        assert np.array_equal(lean["count"], full["count"])
 
 
 def test_batch_tokeniser_and_caller_supplied_embeddings(ucc_index, monkeypatch):
@@ -453,6 +463,21 @@ def test_batch_tokeniser_and_caller_supplied_embeddings(ucc_index, monkeypatch):
     monkeypatch.setattr(text, "_custom_cut", lambda s_: calls.append(s_) or text.jieba_cut_restated(s_))
     t2, p2, _ = r.bm25.term_ids_batch(qs[:4])
     assert len(calls) == 4 and np.array_equal(t2, terms[: q_ptr[4]]) and np.array_equal(p2, q_ptr[:5])
+    # with jieba installed (every deployment of the reference) the batch STAYS native: only a query that holds one of
+    # the ASCII entries of jieba's dictionary goes to jieba itself — per query, not per process
+    monkeypatch.setattr(text, "_custom_cut", None)
+    seen = []
+
+    class FakeJieba:
+        @staticmethod
+        def cut(s_):
+            seen.append(s_)
+            return text.jieba_cut_restated(s_)
+    monkeypatch.setattr(text, "HAVE_JIEBA", True)
+    monkeypatch.setattr(text, "_jieba", FakeJieba)
+    t3, p3, e3 = r.bm25.term_ids_batch(qs)
+    assert seen == ["rate of 3.5% p.a. (a) C++"] and e3.all()
+    assert np.array_equal(t3, terms) and np.array_equal(p3, q_ptr)
 
 
 def test_error_conventions(tmp_path):
