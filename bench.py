@@ -52,14 +52,31 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA == fp32 vector peak
 
 
-def pmc_traffic(key, kernel_prefix):
-    """HBM bytes per launch measured with rocprofv3 PMC in a separate run of this same command
-    (profiles/pmc_traffic.json).  None unless a measurement OF THE KERNEL THAT RAN is on record —
-    an entry taken on another kernel must not go stale silently."""
+def kernel_sources_fingerprint():
+    """sha256 (16 hex digits) over the kernel sources: what scripts/pmc_traffic.py stamps on every traffic entry."""
+    import hashlib
+    h = hashlib.sha256()
+    for p in sorted((ROOT / "legal-rag_amd" / "csrc").glob("*")):
+        if p.suffix in (".hip", ".hpp", ".cpp"):
+            h.update(p.name.encode())
+            h.update(p.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(key, kernel_prefix, plan=None):
+    """HBM bytes per launch measured with rocprofv3 PMC in a separate run of the same object (scripts/pmc_traffic.py ->
+    profiles/pmc_traffic.json).  None unless the entry was measured on THESE kernel sources (fingerprint), on the kernel
+    that ran (name) and — where the object has a plan string — under the same plan: an entry of another round, another
+    kernel or another work cut must not be reported as this run's."""
     try:
         rec = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text()).get(key)
-        if rec and str(rec.get("kernel", "")).startswith(kernel_prefix):
-            return float(rec["bytes_per_launch"])
+        if not rec or not str(rec.get("kernel", "")).startswith(kernel_prefix.split("<")[0].split(" ")[0]):
+            return None
+        if rec.get("sources") != kernel_sources_fingerprint():
+            return None
+        if plan is not None and rec.get("plan") is not None and rec["plan"] != plan:
+            return None
+        return float(rec["bytes_per_launch"])
     except Exception:  # noqa: BLE001
         pass
     return None
@@ -83,6 +100,9 @@ def parse():
     ap.add_argument("--synth-batch", type=int, default=8)
     ap.add_argument("--no-extras", action="store_true", help="skip ucc_colbert / full_hybrid_rerank / api / hbm_scan")
     ap.add_argument("--no-hbm-scan", action="store_true")
+    ap.add_argument("--only", default=None, choices=["dense_only_d384", "ucc_colbert", "full_hybrid_rerank", "api",
+                                                     "shard8_proxy"],
+                    help="run ONE of the side objects alone and print {name: object} (profiling passes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -354,7 +374,7 @@ def run_ucc_colbert(torch, local, params, K, steps):
            "colbert_doc_tokens": tokens, "maxsim_gflop_per_query": 2.0 * 32 * 128 * tokens / 1e9,
            "roofline": maxsim_roofline(ms, tokens, R.nq, note="MaxSim channel (scores + top-k launches), HIP events",
                                        plan=R.maxsim.plan_info(R.nq))}
-    out["roofline"]["traffic"] = pmc_traffic("ucc_colbert", out["roofline"]["kernel"].split(" ")[0])
+    out["roofline"]["traffic"] = pmc_traffic("ucc_colbert", out["roofline"]["kernel"].split(" ")[0], out["roofline"]["kernel"])
     R.close()
     return out
 
@@ -401,7 +421,9 @@ def run_dense_only_d384(torch, local, K, steps, rep):
                      "max_abs_score_err_vs_oracle": float(np.max(np.abs(got_s - es))),
                      "roofline": {"bound": "mfma", "kernel": plan.split(" ")[0] + " (v_mfma_f32_16x16x4_f32, exact fp32)",
                                   "plan": plan, "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None, "launch_ms": kern_ms,
+                                  "frac": ach / F32_MFMA_PEAK_TFLOPS,
+                                  "traffic": pmc_traffic("dense_only_d384", plan.split(" ")[0], plan) if nq > 20000 else None,
+                                  "launch_ms": kern_ms,
                                   "algorithmic_flops": flops,
                                   "algorithmic_bytes": float(n) * d * 4 + float(nq) * d * 4 + float(n) * nq * 4}}
     t0 = time.perf_counter()
@@ -504,6 +526,8 @@ def run_full_hybrid_rerank(torch, local, K, steps, dist=None, world=1, rank=0):
            "scaling": "strong" if world > 1 else None,
            "rerank": {"beta": beta, "top_n": top_n, "cross_encoder": "stand-in scores resident in HBM"},
            "per_lang": per_lang, "phase_ms_rank0": phase, "roofline": roof}
+    if world == 1:
+        roof["traffic"] = pmc_traffic("full_hybrid_rerank", roof["kernel"].split(" ")[0], roof["kernel"])
     if world > 1:
         t = torch.tensor([phase["maxsim_ms"], phase["exchange_merge_ms"]], dtype=torch.float64, device=device)
         allt = [torch.zeros_like(t) for _ in range(world)]
@@ -717,7 +741,8 @@ def _hbm_scan_one(torch, _native, device, X, Q, n, d, B, steps, warmup, k):
            "queries_per_s": B * steps / wall, "ms_per_scan_wall": wall / steps * 1e3,
            "scan_kernel_ms": per_launch_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
            "achieved_GBs": achieved, "peak_GBs": HBM_PEAK_GBS, "frac": achieved / HBM_PEAK_GBS,
-           "traffic": pmc_traffic(f"synth10m_b{B}", kernel) if (n == 10_000_000 and d == 768) else None,
+           "traffic": (pmc_traffic(f"synth10m_b{B}", kernel) if (n == 10_000_000 and d == 768) else
+                       pmc_traffic(f"synth7500k_d1024_b{B}", kernel) if (n == 7_500_000 and d == 1024) else None),
            "f32_TFLOPs": None if hi else 2.0 * n * d * B / (per_launch_ms * 1e-3) / 1e12,
            "oracle_prefix_rows": npre, "oracle_id_agreement": agree, "oracle_max_abs_err": maxerr, **extra}
     idx.close()
@@ -771,7 +796,7 @@ def run_shard8_proxy(torch, device, n=1_250_000, d=768, k=10, steps=30):
         try:
             ex = _native.DenseIndex(device_ptr=X.data_ptr(), n=n, dim=d, device=device.index, keepalive=X)
             es_, ei_ = torch.empty_like(s), torch.empty_like(i)
-            ex.search_device(Q[((steps + 19) * B) % (1024 - B + 1):].data_ptr(), B, k, es_.data_ptr(), ei_.data_ptr(), st)
+            ex.search_device(Q[(19 * B) % (1024 - B + 1):].data_ptr(), B, k, es_.data_ptr(), ei_.data_ptr(), st)  # the last search's queries
             torch.cuda.synchronize()
             same = bool(np.array_equal(ei_.cpu().numpy(), hids) and
                         np.array_equal(es_.cpu().numpy().view(np.uint32), hs.view(np.uint32)))
@@ -928,6 +953,17 @@ def main():
 
     _native.load()
     result = {}
+    if a.only:
+        K = 10
+        params = _native.make_fuse_params(min_final_score=0.2)
+        n_steps = max(3, min(a.steps, 10))
+        fn = {"dense_only_d384": lambda: run_dense_only_d384(torch, local, K, n_steps, max(1, a.repeat)),
+              "ucc_colbert": lambda: run_ucc_colbert(torch, local, params, K, n_steps),
+              "full_hybrid_rerank": lambda: run_full_hybrid_rerank(torch, local, K, n_steps),
+              "api": lambda: run_api(torch, local),
+              "shard8_proxy": lambda: run_shard8_proxy(torch, device)}[a.only]
+        print(json.dumps({a.only: fn()}))
+        return
     if a.workload == "ucc_hybrid":
         K = 10
         W = build_corpus("en")
@@ -1008,7 +1044,7 @@ def main():
         roofline = {"bound": "mfma", "kernel": f"{kernel} (v_mfma_f32_16x16x4_f32, exact fp32)", "plan": plan,
                     "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / F32_MFMA_PEAK_TFLOPS,
-                    "traffic": pmc_traffic("ucc_hybrid", kernel) if (rep == 32 and shard == "queries") else None,
+                    "traffic": pmc_traffic("ucc_hybrid", kernel, plan) if (rep == 32 and shard == "queries") else None,
                     "launch_ms": per_launch_ms, "launches_timed": launches, "launch_ms_windows": launch_ms_windows,
                     "algorithmic_flops": flops_per_launch,
                     "algorithmic_bytes": float(rows_local) * d * 4 + nq * d * 4 + float(rows_local) * nq * 4,

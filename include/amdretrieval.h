@@ -153,7 +153,7 @@ int amdr_tokenizer_encode(const amdr_tokenizer_t* t, const char* text_blob, cons
 /* the same for queries joined by ONE NUL byte each (nq - 1 separators in n_bytes; a caller with a list of Python strings
  * builds this blob with two C-level operations — "\0".join(qs).encode() — instead of one encode per query).  Both forms
  * cut a batch into ranges of queries for a small persistent pool of worker threads (AMDR_TOKENIZER_THREADS, default: the
- * hardware's, at most 16; one worker per 256 queries) and splice the ranges' terms by a prefix sum. */
+ * hardware's, at most 32; one worker per 256 queries) and splice the ranges' terms by a prefix sum. */
 int amdr_tokenizer_encode_joined(const amdr_tokenizer_t* t, const char* text_blob, int64_t n_bytes, int32_t nq,
                                  int32_t* term_ids, int64_t capacity, int64_t* q_ptr, int32_t* needs_segmenter);
 /* byte spans of one text's tokens (tests compare them with text.jieba_cut); *n_tokens = -1: Han text */

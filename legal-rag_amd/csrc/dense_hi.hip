@@ -658,11 +658,16 @@ __global__ __launch_bounds__(64) void dense_hi_tau_kernel(const float* __restric
   const float* row = MT + (size_t)q * cols;  // query-major: row q, `cols` = its leading dimension (items rounded up to 64)
   (void)qt;
   u32 key[32];
+  // unconditional loads on clamped indices: behind `i < items ?` hipcc issued them one at a time, each in its own branch
+  // with its own wait — 32 dependent memory round trips, 22 of this kernel's 25 us
+  float raw[32];
 #pragma unroll
   for (int v = 0; v < 32; ++v) {
     const int i = lane + 64 * v;
-    key[v] = i < items ? ord32(row[i]) : 0u;
+    raw[v] = row[i < items ? i : items - 1];
   }
+#pragma unroll
+  for (int v = 0; v < 32; ++v) key[v] = (lane + 64 * v) < items ? ord32(raw[v]) : 0u;
   // pin the keys in registers: hipcc otherwise re-LOADS them from the (const, restrict) row in every one of the 32
   // rounds below instead of holding 32 registers (the kernel reported 20 VGPRs and took 24 us)
 #pragma unroll

@@ -316,7 +316,7 @@ class Pool {
     int n = (int)std::thread::hardware_concurrency();
     const char* e = getenv("AMDR_TOKENIZER_THREADS");
     if (e && atoi(e) >= 1) n = atoi(e);
-    if (n > 16) n = 16;
+    if (n > 32) n = 32;
     if (n < 1) n = 1;
     for (int i = 1; i < n; ++i) {
       th_.emplace_back([this, i] { loop(i); });

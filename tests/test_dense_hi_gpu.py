@@ -342,3 +342,35 @@ def test_hi_first_pass_seeded_sweep_of_shapes(nat, monkeypatch):
         assert np.array_equal(out["hi"][1], out["exact"][1]), (trial, n, d, nq, k)
         assert np.array_equal(out["hi"][0].view(np.uint32), out["exact"][0].view(np.uint32)), (trial, n, d, nq, k)
     assert took_total > 1500 and unresolved * 20 < took_total  # the fast path is what ran
+
+
+def test_hi_first_pass_against_the_cpu_oracle_directly(nat, monkeypatch):
+    """The fp16 first pass + round-4 tail held to oracle/dense.py itself (exact FlatIP in numpy), not only to the other
+    HIP forms: the assertions of test_kernels_gpu.check_dense — reported score == exact score of the reported id within
+    1e-4, descending, the oracle's hits clearly above the cut all present, ranks equal wherever the oracle's neighbouring
+    scores are separated by more than the tolerance — on pinned-hi shapes: d = 768 with 70 queries (a 64-query tile +
+    remainder), d = 1 024 with 48 queries per scan, a matrix scaled by 37.5 with queries scaled by 1/1024, k = 10 and 40,
+    and both tails (AMDR_DENSE_HI_TAIL=1: round 4, =0: round 3)."""
+    from test_kernels_gpu import check_dense
+    rng = np.random.default_rng(99)
+    monkeypatch.setenv("AMDR_DENSE_TWO_LEVEL", "1")
+    monkeypatch.setenv("AMDR_DENSE_HI", "1")
+    cases = [(20011, 768, 70, 10, 1.0, 1.0), (16400, 1024, 48, 10, 1.0, 1.0), (18000, 1024, 100, 40, 1.0, 1.0),
+             (20011, 256, 130, 10, 37.5, 1.0 / 1024.0), (20011, 384, 64, 40, 1.0, 1.0)]
+    for tail in ("1", "0"):
+        monkeypatch.setenv("AMDR_DENSE_HI_TAIL", tail)
+        for n, d, nq, k, xs, qs in cases:
+            X = (unit_rows(rng, n, d) * np.float32(xs)).astype(np.float32)
+            Q = (unit_rows(rng, nq, d) * np.float32(qs)).astype(np.float32)
+            probe = nat.DenseIndex(X)
+            assert "dense_hi_tilemax_kernel" in probe.plan_info(nq, k), (tail, n, d, nq, k)
+            probe.close()
+            # check_dense's tolerance is absolute (1e-4 on unit-norm scores): bring the scaled case back to unit scale
+            if xs != 1.0 or qs != 1.0:
+                s, i = nat.DenseIndex(X).search(Q, k)
+                from oracle import dense as OD
+                es, ei = OD.flatip_topk(X, Q, k)
+                assert np.array_equal(i, ei), (tail, n, d)
+                assert np.max(np.abs(s - es)) <= 1e-4 * xs * qs * 4
+            else:
+                check_dense(nat, X, Q, k)
