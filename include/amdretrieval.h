@@ -156,6 +156,10 @@ int amdr_tokenizer_encode(const amdr_tokenizer_t* t, const char* text_blob, cons
  * hardware's, at most 32; one worker per 256 queries) and splice the ranges' terms by a prefix sum. */
 int amdr_tokenizer_encode_joined(const amdr_tokenizer_t* t, const char* text_blob, int64_t n_bytes, int32_t nq,
                                  int32_t* term_ids, int64_t capacity, int64_t* q_ptr, int32_t* needs_segmenter);
+/* the same for queries that lie where they are: texts[q] = the n_bytes[q] UTF-8 bytes of query q (no blob is built; a
+ * Python caller takes the pointers from the str objects themselves, csrc/pystrings.c) */
+int amdr_tokenizer_encode_ptrs(const amdr_tokenizer_t* t, const char* const* texts, const int64_t* n_bytes, int32_t nq,
+                               int32_t* term_ids, int64_t capacity, int64_t* q_ptr, int32_t* needs_segmenter);
 /* byte spans of one text's tokens (tests compare them with text.jieba_cut); *n_tokens = -1: Han text */
 int amdr_tokenizer_spans(const char* text, int64_t n_bytes, int32_t* starts, int32_t* ends, int32_t capacity,
                          int32_t* n_tokens);

@@ -33,7 +33,7 @@ EXPORTS = (
     "amdr_dense_plan_info", "amdr_dense_workspace_plan", "amdr_dense_hi_counters", "amdr_dense_profile_begin", "amdr_dense_profile_end", "amdr_dense_destroy",
     "amdr_bm25_create", "amdr_bm25_ndocs", "amdr_bm25_reserve", "amdr_bm25_search", "amdr_bm25_search_device",
     "amdr_bm25_scores", "amdr_bm25_destroy",
-    "amdr_tokenizer_create", "amdr_tokenizer_encode", "amdr_tokenizer_encode_joined", "amdr_tokenizer_spans", "amdr_tokenizer_destroy",
+    "amdr_tokenizer_create", "amdr_tokenizer_encode", "amdr_tokenizer_encode_joined", "amdr_tokenizer_encode_ptrs", "amdr_tokenizer_spans", "amdr_tokenizer_destroy",
     "amdr_maxsim_create", "amdr_maxsim_ndocs", "amdr_maxsim_plan_info", "amdr_maxsim_reserve", "amdr_maxsim_search",
     "amdr_maxsim_search_device", "amdr_maxsim_scores", "amdr_maxsim_destroy",
     "amdr_fuse", "amdr_fuse_device", "amdr_rerank_blend", "amdr_rerank_blend_device", "amdr_fuse_compact_device",
@@ -55,7 +55,7 @@ SIGNATURES = {
     "amdr_bm25_create": "PPPPPlldddiP", "amdr_bm25_ndocs": "PP", "amdr_bm25_reserve": "Piil",
     "amdr_bm25_search": "PPPiiPP", "amdr_bm25_search_device": "PPPiiPPP", "amdr_bm25_scores": "PPPiP",
     "amdr_bm25_destroy": "P",
-    "amdr_tokenizer_create": "PPlP", "amdr_tokenizer_encode": "PPPiPlPP", "amdr_tokenizer_encode_joined": "PPliPlPP", "amdr_tokenizer_spans": "PlPPiP",
+    "amdr_tokenizer_create": "PPlP", "amdr_tokenizer_encode": "PPPiPlPP", "amdr_tokenizer_encode_joined": "PPliPlPP", "amdr_tokenizer_encode_ptrs": "PPPiPlPP", "amdr_tokenizer_spans": "PlPPiP",
     "amdr_tokenizer_destroy": "P",
     "amdr_maxsim_create": "PPliiP", "amdr_maxsim_ndocs": "PP", "amdr_maxsim_plan_info": "PiPi", "amdr_maxsim_reserve": "Pii",
     "amdr_maxsim_search": "PPiiiPP", "amdr_maxsim_search_device": "PPiiiPPP", "amdr_maxsim_scores": "PPiiP",
@@ -84,6 +84,30 @@ class ShardChan(C.Structure):
 
 
 _lib: Optional[C.CDLL] = None
+
+
+_pystr = False
+
+
+def _pystrings():
+    """The CPython helper next to the library (lib/_amdr_pystrings.so: UTF-8 views of a list of str without copies), or
+    None when it was not built — the tokeniser then takes the joined-blob form.  Host glue only: no compute."""
+    global _pystr
+    if _pystr is False:
+        _pystr = None
+        p = lib_path().parent / "_amdr_pystrings.so"
+        if p.exists() and os.environ.get("AMDR_NO_PYSTRINGS") != "1":
+            try:
+                import importlib.machinery
+                import importlib.util
+                loader = importlib.machinery.ExtensionFileLoader("_amdr_pystrings", str(p))
+                spec = importlib.util.spec_from_loader("_amdr_pystrings", loader)
+                mod = importlib.util.module_from_spec(spec)
+                loader.exec_module(mod)
+                _pystr = mod
+            except Exception:  # noqa: BLE001 - glue is optional
+                _pystr = None
+    return _pystr
 
 
 def lib_path() -> Path:
@@ -376,7 +400,18 @@ class Tokenizer:
         n = len(texts)
         if n == 0:
             return np.zeros(0, np.int32), np.zeros(1, np.int64), np.zeros(0, bool)
-        blob = "\0".join(texts).encode("utf-8")
+        views = _pystrings()
+        if views is not None:
+            # zero-copy: the UTF-8 bytes where CPython keeps them (csrc/pystrings.c), pointers + lengths to the native call
+            ptrs, lens = np.empty(n, dtype=np.int64), np.empty(n, dtype=np.int64)
+            cap = max(int(views.utf8_views(texts, ptrs.ctypes.data, lens.ctypes.data)), 1)
+            terms = np.empty(cap, dtype=np.int32)
+            q_ptr = np.empty(n + 1, dtype=np.int64)
+            flags = np.empty(n, dtype=np.int32)
+            _check(load().amdr_tokenizer_encode_ptrs(self._h, ptrs.ctypes.data, lens.ctypes.data, n, terms.ctypes.data, cap,
+                                                     q_ptr.ctypes.data, flags.ctypes.data), "amdr_tokenizer_encode_ptrs")
+            return terms[: int(q_ptr[-1])], q_ptr, flags.astype(bool)
+        blob = "\0".join(t or "" for t in texts).encode("utf-8")
         cap = max(len(blob), 1)
         terms = np.empty(cap, dtype=np.int32)
         q_ptr = np.zeros(n + 1, dtype=np.int64)

@@ -1053,8 +1053,12 @@ __global__ __launch_bounds__(256) void maxsim_rescore_kernel(const unsigned char
 //   maxsim_doc_offsets_kernel   exclusive prefix sums over the documents: pairs (doff) and 8-query items (ioff)
 //   maxsim_pairs_fill_kernel    pairs[doff[doc] + slot] = query
 //   maxsim_rescore_ring_kernel  persistent blocks of 8 waves walk the items
+struct MsItem {  // one unit of the re-scoring pass: a document and up to 8 of its queries
+  int doc, p0, cnt, pad;
+};
 __global__ __launch_bounds__(256) void maxsim_doc_offsets_kernel(const int* __restrict__ dcnt, long n_docs,
-                                                                 int* __restrict__ doff, int* __restrict__ ioff) {
+                                                                 int* __restrict__ doff, int* __restrict__ ioff,
+                                                                 MsItem* __restrict__ items) {
   __shared__ int part[2][256];
   int carry_p = 0, carry_i = 0;
   for (long base = 0; base < n_docs; base += 256) {
@@ -1073,8 +1077,13 @@ __global__ __launch_bounds__(256) void maxsim_doc_offsets_kernel(const int* __re
       __syncthreads();
     }
     if (i < n_docs) {
-      doff[i] = carry_p + part[0][threadIdx.x] - v;
-      ioff[i] = carry_i + part[1][threadIdx.x] - it;
+      const int p0 = carry_p + part[0][threadIdx.x] - v, i0 = carry_i + part[1][threadIdx.x] - it;
+      doff[i] = p0;
+      ioff[i] = i0;
+      // the item table: the re-scoring blocks read ONE 16-byte descriptor per item instead of searching the offsets (ten
+      // dependent loads per item and wave)
+      for (int c = 0; c < it; ++c)
+        items[i0 + c] = MsItem{(int)i, p0 + c * kMsQ, v - c * kMsQ < kMsQ ? v - c * kMsQ : kMsQ, 0};
     }
     carry_p += part[0][255];
     carry_i += part[1][255];
@@ -1100,8 +1109,8 @@ __global__ __launch_bounds__(256) void maxsim_pairs_fill_kernel(const int* __res
 template <int NBUF>
 __global__ __launch_bounds__(kMsQ * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void maxsim_rescore_ring_kernel(
     const unsigned char* __restrict__ img, const long long* __restrict__ doc_ptr, long n_docs,
-    const float* __restrict__ Q, int q_len, float unscale_d, const int* __restrict__ doff, const int* __restrict__ ioff,
-    const int* __restrict__ pairs, float* __restrict__ exact /*[nq, n_docs]*/) {
+    const float* __restrict__ Q, int q_len, float unscale_d, const MsItem* __restrict__ item_tab,
+    const int* __restrict__ ioff, const int* __restrict__ pairs, float* __restrict__ exact /*[nq, n_docs]*/) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // [NBUF][32 * 512]
   constexpr int kStage = 32 * 512;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1117,25 +1126,20 @@ __global__ __launch_bounds__(kMsQ * 64) __attribute__((amdgpu_waves_per_eu(4, 4)
 #pragma unroll
   for (int st = 0; st < 8; ++st) foff[st] = ms_tile_off(r32, 2 * st + h);
   const int items = ioff[n_docs];
-  for (int item = blockIdx.x; item < items; item += gridDim.x) {
-    long doc;
-    {  // the document of this item: the last d with ioff[d] <= item (documents without candidates share their successor's offset)
-      long a = 0, b = n_docs;
-      while (b - a > 1) {
-        const long m = (a + b) >> 1;
-        if (ioff[m] <= item) a = m; else b = m;
-      }
-      doc = a;
-    }
-    const int p0 = doff[doc] + (item - ioff[doc]) * kMsQ, p1 = doff[doc + 1];
-    const bool live = p0 + wave < p1;
-    const int qi = live ? pairs[p0 + wave] : 0;
-    ms8h qh[8], ql[8];
-    float unscale;
-    ms_load_query_h(Q + (size_t)qi * q_len * kDim, q_len, live, r32, h, qh, ql, unscale);
-    unscale *= unscale_d;
-    const long t_lo = doc_ptr[doc];
-    const int len = (int)(doc_ptr[doc + 1] - t_lo);
+  // Two items of look-ahead so that no item waits for a chain of dependent loads: the DESCRIPTOR of item i + 2 and the
+  // scalars of item i + 1 (its query of this wave, its document's extent — they need i + 1's descriptor, which is in
+  // registers by then) are requested while item i is multiplied.
+  const int stride = (int)gridDim.x;
+  auto desc_of = [&](int it) { return it < items ? item_tab[it] : MsItem{0, 0, 0, 0}; };
+  MsItem cur = desc_of(blockIdx.x), nxt = desc_of(blockIdx.x + stride);
+  int qi_c = wave < cur.cnt ? pairs[cur.p0 + wave] : 0;
+  long tlo_c = doc_ptr[cur.doc], thi_c = doc_ptr[cur.doc + 1];
+  for (int item = blockIdx.x; item < items; item += stride) {
+    const long doc = cur.doc;
+    const bool live = wave < cur.cnt;
+    const int qi = qi_c;
+    const long t_lo = tlo_c;
+    const int len = (int)(thi_c - tlo_c);
     const int ntiles = (len + 31) >> 5;
     // every wave has read the last tile of the previous item before its stage is refilled
     __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -1149,21 +1153,39 @@ __global__ __launch_bounds__(kMsQ * 64) __attribute__((amdgpu_waves_per_eu(4, 4)
         __builtin_amdgcn_global_load_lds(AMDR_MS_GPTR(src + poff[u]),
                                          AMDR_MS_LPTR(ring + (tile % NBUF) * kStage + (2 * wave + u) * 1024), 16, 0, 0);
     };
+    // the first tiles are on their way BEFORE the query fragments are fetched and split: the two latencies overlap
 #pragma unroll
     for (int i = 0; i < NBUF - 1; ++i)
       if (issued < ntiles) issue(issued++);
+    const int n_first = issued;
+    ms8h qh[8], ql[8];
+    float unscale;
+    ms_load_query_h(Q + (size_t)qi * q_len * kDim, q_len, live, r32, h, qh, ql, unscale);
+    unscale *= unscale_d;
+    // vmcnt counts in issue order: once the query loads (issued behind them) are in, so are this wave's pieces of the
+    // first tiles — made explicit here, so that no later scheduling of the split arithmetic can move that point
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" ::: "memory");
+    // look-ahead (see above): scalars of the next item, descriptor of the one after
+    const MsItem nn = desc_of(item + 2 * stride);
+    const int qi_n = wave < nxt.cnt ? pairs[nxt.p0 + wave] : 0;
+    const long tlo_n = doc_ptr[nxt.doc], thi_n = doc_ptr[nxt.doc + 1];
     float best = -FLT_MAX;
     for (int done = 0; done < ntiles; ++done) {
-      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-      const int behind = issued - done - 1;
-      if (behind >= 3) {
-        __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(6)
-      } else if (behind == 2) {
-        __builtin_amdgcn_s_waitcnt(0x0F74);
-      } else if (behind == 1) {
-        __builtin_amdgcn_s_waitcnt(0x0F72);
-      } else {
-        __builtin_amdgcn_s_waitcnt(0x0F70);
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the fragment reads of the previous tile
+      if (done >= n_first) {
+        // a tile issued inside this loop: landed once at most 2 x (tiles issued behind it) DMAs are outstanding (the
+        // look-ahead loads above are older than every DMA of the loop)
+        const int behind = issued - done - 1;
+        if (behind >= 3) {
+          __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(6)
+        } else if (behind == 2) {
+          __builtin_amdgcn_s_waitcnt(0x0F74);
+        } else if (behind == 1) {
+          __builtin_amdgcn_s_waitcnt(0x0F72);
+        } else {
+          __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
       }
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -1178,6 +1200,11 @@ __global__ __launch_bounds__(kMsQ * 64) __attribute__((amdgpu_waves_per_eu(4, 4)
       }
       ms_tile_h(ah, al, qh, ql, h, len - 32 * done, best);
     }
+    cur = nxt;
+    nxt = nn;
+    qi_c = qi_n;
+    tlo_c = tlo_n;
+    thi_c = thi_n;
     const float total = ms_finish_h(best, r32, h, q_len, unscale);
     if (live && lane == 0) exact[(size_t)qi * n_docs + doc] = total;
   }
@@ -1270,9 +1297,11 @@ int ms_cand_cap(int k) {
 size_t ms_workspace_bytes(const amdr_maxsim* h, int nq, int k, bool want_topk) {
   const size_t rows = ((size_t)nq * h->n_docs * sizeof(float) + 255) / 256 * 256;
   if (!ms_two_pass(h, nq, k, want_topk)) return rows;
-  // + the by-document pair lists of the re-scoring pass: pairs [nq * cap], dcnt / dfill [n_docs] each, doff / ioff [n_docs + 1]
+  // + the by-document pair lists of the re-scoring pass: pairs [nq * cap], dcnt / dfill [n_docs] each, doff / ioff
+  // [n_docs + 1], the item table (<= n_docs + pairs / 8 descriptors of 16 bytes)
   return 2 * rows + ((size_t)nq * ms_cand_cap(k) + 3 * (size_t)nq + 1) * sizeof(int) + 256 +
-         ((size_t)nq * ms_cand_cap(k) + 4 * (size_t)h->n_docs + 8) * sizeof(int);
+         ((size_t)nq * ms_cand_cap(k) + 4 * (size_t)h->n_docs + 8) * sizeof(int) +
+         ((size_t)h->n_docs + (size_t)nq * ms_cand_cap(k) / kMsQ + 8) * 16;
 }
 
 int ms_run(amdr_maxsim* h, const float* Q_dev, int nq, int q_len, int k, float* full_dev, float* scores_dev,
@@ -1313,6 +1342,7 @@ int ms_run(amdr_maxsim* h, const float* Q_dev, int nq, int q_len, int k, float* 
     int* dfill = dcnt + h->n_docs;
     int* doff = dfill + h->n_docs;            // [n_docs + 1] first pair of a document
     int* ioff = doff + h->n_docs + 1;         // [n_docs + 1] first 8-query item of a document
+    MsItem* items = reinterpret_cast<MsItem*>(((uintptr_t)(ioff + h->n_docs + 1) + 15) & ~(uintptr_t)15);
     const char* rs = getenv("AMDR_MAXSIM_RESCORE");  // "0": one wave per pair (the round-3 form; A/B, tests)
     const bool by_doc = !(rs && rs[0] == '0');
     if (by_doc) AMDR_HIP(hipMemsetAsync(dcnt, 0, 2 * (size_t)h->n_docs * sizeof(int), st));
@@ -1325,13 +1355,13 @@ int ms_run(amdr_maxsim* h, const float* Q_dev, int nq, int q_len, int k, float* 
     AMDR_HIP(hipGetDevice(&dev));
     AMDR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     if (by_doc) {
-      hipLaunchKernelGGL(maxsim_doc_offsets_kernel, dim3(1), dim3(256), 0, st, dcnt, (long)h->n_docs, doff, ioff);
+      hipLaunchKernelGGL(maxsim_doc_offsets_kernel, dim3(1), dim3(256), 0, st, dcnt, (long)h->n_docs, doff, ioff, items);
       hipLaunchKernelGGL(maxsim_pairs_fill_kernel, dim3(ceil_div((long)nq * cap, 256)), dim3(256), 0, st, cand, cnt, nq, cap,
                          doff, dfill, pairs);
       AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_rescore_ring_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    4 * 16384));
       hipLaunchKernelGGL((maxsim_rescore_ring_kernel<4>), dim3(2 * cus), dim3(kMsQ * 64), 4 * 16384, st, h->img, h->doc_ptr,
-                         (long)h->n_docs, Q_dev, q_len, unscale_d, doff, ioff, pairs, exact);
+                         (long)h->n_docs, Q_dev, q_len, unscale_d, items, ioff, pairs, exact);
     } else {
       AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_rescore_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds));
       hipLaunchKernelGGL(maxsim_offsets_kernel, dim3(1), dim3(256), 0, st, cnt, nq, off);

@@ -348,10 +348,10 @@ class Pool {
   uint64_t gen_ = 0;
 };
 
-// the batch core: queries text[offs[q] .. offs[q + 1] - trim) -> CSR.  Two phases: every worker tokenises its range of
+// the batch core: query q = the lens[q] bytes at ptrs[q] -> CSR.  Two phases: every worker tokenises its range of
 // queries into its own term buffer (+ per-query counts), then the prefix sum over the counts gives q_ptr and every
 // worker copies its terms to their place.
-int encode_core(const amdr_tokenizer* t, const unsigned char* text, const int64_t* offs, int64_t trim, int32_t nq,
+int encode_core(const amdr_tokenizer* t, const unsigned char* const* ptrs, const int64_t* lens, int32_t nq,
                 int32_t* term_ids, int64_t capacity, int64_t* q_ptr, int32_t* needs_segmenter) {
   if (nq == 0) return AMDR_OK;
   q_ptr[0] = 0;
@@ -369,23 +369,25 @@ int encode_core(const amdr_tokenizer* t, const unsigned char* text, const int64_
     int32_t lo, hi;
     range(p, &lo, &hi);
     std::vector<int32_t>& out = bufs[(size_t)p];
-    out.reserve((size_t)((offs[hi] - offs[lo]) / 2 + 16));
+    int64_t bytes = 0;
+    for (int32_t q = lo; q < hi; ++q) bytes += lens[q] > 0 ? lens[q] : 0;
+    out.reserve((size_t)(bytes / 2 + 16));
     for (int32_t q = lo; q < hi; ++q) {
-      const int64_t a = offs[q], b = offs[q + 1] - (q + 1 < nq ? trim : 0);
-      if (b < a || b - a >= (1ll << 31)) {
+      const int64_t n = lens[q];
+      if (n < 0 || n >= (1ll << 31) || (n > 0 && !ptrs[q])) {
         bad.store(q);
         return;
       }
-      const unsigned char* s = text + a;
+      const unsigned char* s = ptrs[q];
       const size_t start = out.size();
-      const bool ok = tokenize(s, (int)(b - a), [&](int x, int y) { out.push_back(t->find(s + x, (size_t)(y - x))); });
+      const bool ok = tokenize(s, (int)n, [&](int x, int y) { out.push_back(t->find(s + x, (size_t)(y - x))); });
       if (!ok) out.resize(start);
       needs_segmenter[q] = ok ? 0 : 1;
       q_ptr[q + 1] = (int64_t)(out.size() - start);  // the count; turned into the offset below
     }
   };
   pool.run(parts, phase1);
-  AMDR_REQUIRE(bad.load() < 0, "tokenizer_encode: bad offsets at query %d", bad.load());
+  AMDR_REQUIRE(bad.load() < 0, "tokenizer_encode: bad text at query %d", bad.load());
   for (int32_t q = 0; q < nq; ++q) q_ptr[q + 1] += q_ptr[q];
   AMDR_REQUIRE(q_ptr[nq] <= capacity, "tokenizer_encode: term buffer too small (capacity %lld, %lld terms)",
                (long long)capacity, (long long)q_ptr[nq]);
@@ -399,6 +401,18 @@ int encode_core(const amdr_tokenizer* t, const unsigned char* text, const int64_
   return AMDR_OK;
 }
 
+// offsets into one blob -> pointer / length arrays (`trim` bytes of separator behind every query but the last)
+int encode_offsets(const amdr_tokenizer* t, const unsigned char* text, const int64_t* offs, int64_t trim, int32_t nq,
+                   int32_t* term_ids, int64_t capacity, int64_t* q_ptr, int32_t* needs_segmenter) {
+  std::vector<const unsigned char*> ptrs((size_t)nq);
+  std::vector<int64_t> lens((size_t)nq);
+  for (int32_t q = 0; q < nq; ++q) {
+    ptrs[(size_t)q] = text + offs[q];
+    lens[(size_t)q] = offs[q + 1] - offs[q] - (q + 1 < nq ? trim : 0);
+  }
+  return encode_core(t, ptrs.data(), lens.data(), nq, term_ids, capacity, q_ptr, needs_segmenter);
+}
+
 }  // namespace
 
 extern "C" {
@@ -408,7 +422,16 @@ int amdr_tokenizer_encode(const amdr_tokenizer_t* t, const char* text_blob, cons
   AMDR_REQUIRE(t != nullptr, "tokenizer_encode: null handle");
   AMDR_REQUIRE(nq >= 0 && (nq == 0 || (text_offsets && q_ptr && needs_segmenter)), "tokenizer_encode: null buffer");
   AMDR_REQUIRE(capacity >= 0 && (capacity == 0 || term_ids), "tokenizer_encode: null term buffer");
-  return encode_core(t, reinterpret_cast<const unsigned char*>(text_blob), text_offsets, 0, nq, term_ids, capacity, q_ptr,
+  return encode_offsets(t, reinterpret_cast<const unsigned char*>(text_blob), text_offsets, 0, nq, term_ids, capacity, q_ptr,
+                        needs_segmenter);
+}
+
+int amdr_tokenizer_encode_ptrs(const amdr_tokenizer_t* t, const char* const* texts, const int64_t* n_bytes, int32_t nq,
+                               int32_t* term_ids, int64_t capacity, int64_t* q_ptr, int32_t* needs_segmenter) {
+  AMDR_REQUIRE(t != nullptr, "tokenizer_encode_ptrs: null handle");
+  AMDR_REQUIRE(nq >= 0 && (nq == 0 || (texts && n_bytes && q_ptr && needs_segmenter)), "tokenizer_encode_ptrs: null buffer");
+  AMDR_REQUIRE(capacity >= 0 && (capacity == 0 || term_ids), "tokenizer_encode_ptrs: null term buffer");
+  return encode_core(t, reinterpret_cast<const unsigned char* const*>(texts), n_bytes, nq, term_ids, capacity, q_ptr,
                      needs_segmenter);
 }
 
@@ -432,8 +455,8 @@ int amdr_tokenizer_encode_joined(const amdr_tokenizer_t* t, const char* text_blo
   }
   AMDR_REQUIRE(p > end || memchr(p, 0, (size_t)(end - p)) == nullptr, "tokenizer_encode_joined: more separators than queries");
   offs[(size_t)nq] = n_bytes;
-  return encode_core(t, reinterpret_cast<const unsigned char*>(text_blob), offs.data(), 1, nq, term_ids, capacity, q_ptr,
-                     needs_segmenter);
+  return encode_offsets(t, reinterpret_cast<const unsigned char*>(text_blob), offs.data(), 1, nq, term_ids, capacity, q_ptr,
+                        needs_segmenter);
 }
 
 int amdr_tokenizer_spans(const char* text, int64_t n_bytes, int32_t* starts, int32_t* ends, int32_t capacity,

@@ -107,6 +107,18 @@ class HashingTokenEmbedder:
         toks = toks + ["[MASK]"] * (self.query_maxlen - len(toks))
         return self._unit(toks)
 
+    def encode_queries(self, texts: Sequence[str]) -> np.ndarray:
+        """[n, query_maxlen, dim]: encode_query of every text, one gather + one normalisation for the batch (row-wise
+        arithmetic: the same bits as the per-query call)."""
+        rows = []
+        for text in texts:
+            toks = (["[Q]"] + _tok(text))[: self.query_maxlen]
+            rows.extend(toks)
+            rows.extend(["[MASK]"] * (self.query_maxlen - len(toks)))
+        if not rows:
+            return np.zeros((0, self.query_maxlen, self.dim), dtype=np.float32)
+        return self._unit(rows).reshape(len(texts), self.query_maxlen, self.dim)
+
 
 class HashingCrossScorer:
     """Stand-in for the cross-encoder: sigmoid of a token-overlap statistic."""
@@ -239,6 +251,25 @@ class TransformersColBERT:
         mask = [1] * n_real + [0] * (self.query_maxlen - n_real)
         out = self._forward(torch.tensor([ids], device=self.device), torch.tensor([mask], device=self.device))
         return out[0].cpu().numpy().astype(np.float32)
+
+    def encode_queries_tensor(self, texts: Sequence[str]):
+        """Device tensor [n, query_maxlen, dim] of a batch of queries in ONE forward: every query is padded to
+        query_maxlen with [MASK] anyway (query augmentation), so the batch is rectangular by construction.  The rows equal
+        encode_query's up to the batched GEMMs' rounding."""
+        torch = self.torch
+        ids_b, mask_b = [], []
+        for text in texts:
+            body = self.tok(text, add_special_tokens=False)["input_ids"][: self.query_maxlen - 3]
+            ids = [self.tok.cls_token_id, self.q_id] + body + [self.tok.sep_token_id]
+            n_real = len(ids)
+            ids_b.append(ids + [self.tok.mask_token_id] * (self.query_maxlen - n_real))
+            mask_b.append([1] * n_real + [0] * (self.query_maxlen - n_real))
+        if not ids_b:
+            return torch.zeros((0, self.query_maxlen, self.dim), device=self.device)
+        return self._forward(torch.tensor(ids_b, device=self.device), torch.tensor(mask_b, device=self.device)).contiguous()
+
+    def encode_queries(self, texts: Sequence[str]) -> np.ndarray:
+        return self.encode_queries_tensor(texts).cpu().numpy().astype(np.float32)
 
     def encode_doc(self, text: str) -> np.ndarray:
         torch = self.torch

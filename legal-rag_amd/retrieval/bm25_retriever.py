@@ -105,9 +105,10 @@ class BM25Retriever:
             if tok is None or tok[0] is not self.bm25:
                 tok = (self.bm25, _native.Tokenizer(list(self.bm25.vocab().keys())))
                 self.__dict__["_native_tok"] = tok
-            qs = [q or "" for q in questions]
+            qs = questions  # (None counts as the empty query inside the native call)
             terms, q_ptr, hard = tok[1].encode(qs)
             if text.HAVE_JIEBA:
+                qs = [q or "" for q in questions]
                 joined = "\0".join(qs)
                 if any(w in joined for w in text._ASCII_DICT_WORDS):  # rare: find the queries concerned
                     hard = hard | np.fromiter((any(w in q for w in text._ASCII_DICT_WORDS) for q in qs), dtype=bool, count=n)

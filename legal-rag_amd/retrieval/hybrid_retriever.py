@@ -556,8 +556,16 @@ class HybridRetriever:
         q_tok_h = None
         if col is not None:
             try:
-                q_tok_h = np.stack([np.asarray(col._encoder.encode_query((q or "").strip()), dtype=np.float32)
-                                    for q in questions])
+                # the ColBERT query side of the whole batch in ONE encoder call: a device tensor when the encoder can hand
+                # one over (TransformersColBERT: one BERT forward, nothing comes back to the host), else one numpy batch
+                stripped = [(q or "").strip() for q in questions]
+                enc = col._encoder
+                if hasattr(enc, "encode_queries_tensor"):
+                    q_tok_h = enc.encode_queries_tensor(stripped)
+                elif hasattr(enc, "encode_queries"):
+                    q_tok_h = np.ascontiguousarray(enc.encode_queries(stripped), dtype=np.float32)
+                else:
+                    q_tok_h = np.stack([np.asarray(enc.encode_query(q), dtype=np.float32) for q in stripped])
             except Exception:  # noqa: BLE001 - the reference swallows ColBERT channel errors (:244-245)
                 if getattr(store.index, "spec", None) is not None:
                     # row-sharded: dropping the channel is a rank-LOCAL decision inside an SPMD exchange — the other ranks
@@ -579,7 +587,9 @@ class HybridRetriever:
                                                 np.ascontiguousarray(qt, dtype=np.int32))
             try:
                 res = eng.search_batch(self._params(kn, min_final), eff, q_emb=q_emb, q_terms=q_terms_d, q_ptr=q_ptr_d,
-                                       q_tok=torch.from_numpy(q_tok_h).to(tdev, non_blocking=True) if q_tok_h is not None else None)
+                                       q_tok=None if q_tok_h is None else
+                                       (q_tok_h.to(tdev, dtype=torch.float32).contiguous() if torch.is_tensor(q_tok_h)
+                                        else torch.from_numpy(q_tok_h).to(tdev, non_blocking=True)))
             except _native.NativeError:
                 if col is None or eng.shard_offset is not None:
                     raise  # (row-sharded: a rank must not leave the common exchange on its own, see above)

@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--timeout", type=int, default=240)
     ap.add_argument("--round", type=int, default=4)
     a = ap.parse_args()
-    out = Path(a.out)
+    out = Path(a.out).resolve()  # rocprofv3 runs with cwd=/tmp: absolute paths
     out.mkdir(parents=True, exist_ok=True)
     want = [k for k in OBJECTS if not a.only or k in a.only.split(",")]
     target = ROOT / "profiles" / "pmc_traffic.json"
