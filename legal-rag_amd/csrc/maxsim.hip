@@ -1043,6 +1043,50 @@ __global__ __launch_bounds__(256) void maxsim_rescore_kernel(const unsigned char
   }
 }
 
+// The queries of a batch split ONCE into the [hi | lo] image the document tokens have (512 B per token row, 32 rows per
+// query, rows past q_len zero) + the query's power-of-two unscale: the re-scoring pass takes a query's fragments for
+// every (document, query) item it serves — 15 k times per UCC-en batch — and splitting them in the scoring wave each time
+// (64 loads' worth of fp32 -> 2 x fp16 arithmetic, ~500 vector instructions) cost as much as the item's MFMAs.  Same
+// scale rule and the same ms_split as ms_load_query_h: identical fragments.
+__global__ __launch_bounds__(256) void ms_split_queries_kernel(const float* __restrict__ Q, int q_len,
+                                                               unsigned char* __restrict__ img_q,
+                                                               float* __restrict__ unscale_q) {
+  __shared__ float red[4];
+  const int q = blockIdx.x, tid = threadIdx.x;
+  const float* Qq = Q + (size_t)q * q_len * kDim;
+  float m = 0.f;
+  for (int i = tid; i < q_len * kDim; i += 256) m = fmaxf(m, fabsf(Qq[i]));
+#pragma unroll
+  for (int sft = 1; sft < 64; sft <<= 1) m = fmaxf(m, __shfl_xor(m, sft));
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  int e = 0;
+  if (m > 0.f && m <= FLT_MAX) (void)frexpf(m, &e);
+  const float sc = ldexpf(1.f, -e);
+  if (tid == 0) unscale_q[q] = ldexpf(1.f, e);
+  for (int g = tid; g < 32 * 16; g += 256) {  // (token row, group of 8 components)
+    const int row = g >> 4, grp = g & 15;
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = row < q_len ? Qq[(size_t)row * kDim + 8 * grp + j] : 0.f;
+    ms8h hi, lo;
+    ms_split(x, sc, hi, lo);
+    unsigned char* dst = img_q + ((size_t)q * 32 + row) * 512 + 16 * grp;
+    *reinterpret_cast<ms8h*>(dst) = hi;
+    *reinterpret_cast<ms8h*>(dst + 256) = lo;
+  }
+}
+__device__ __forceinline__ void ms_load_query_img(const unsigned char* __restrict__ img_q, int qi, int r32, int h,
+                                                  ms8h (&qh)[8], ms8h (&ql)[8]) {
+  const unsigned char* p = img_q + ((size_t)qi * 32 + r32) * 512 + 16 * h;
+#pragma unroll
+  for (int st = 0; st < 8; ++st) {
+    qh[st] = *reinterpret_cast<const ms8h*>(p + 32 * st);
+    ql[st] = *reinterpret_cast<const ms8h*>(p + 256 + 32 * st);
+  }
+}
+
 // ---- Pass 2, round 4: the candidate pairs grouped BY DOCUMENT ------------------------------------------------------
 // One wave per pair shared nothing: 15 k pairs x a document image of ~80 KB = 0.93 GB through the fabric for 68 MB of
 // token store (PMC, profiles/r03_pmc.md), 145 us.  A document is a candidate of ~25 queries on the serving corpora, so
@@ -1109,8 +1153,9 @@ __global__ __launch_bounds__(256) void maxsim_pairs_fill_kernel(const int* __res
 template <int NBUF>
 __global__ __launch_bounds__(kMsQ * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void maxsim_rescore_ring_kernel(
     const unsigned char* __restrict__ img, const long long* __restrict__ doc_ptr, long n_docs,
-    const float* __restrict__ Q, int q_len, float unscale_d, const MsItem* __restrict__ item_tab,
-    const int* __restrict__ ioff, const int* __restrict__ pairs, float* __restrict__ exact /*[nq, n_docs]*/) {
+    const unsigned char* __restrict__ img_q, const float* __restrict__ unscale_q, int q_len, float unscale_d,
+    const MsItem* __restrict__ item_tab, const int* __restrict__ ioff, const int* __restrict__ pairs,
+    float* __restrict__ exact /*[nq, n_docs]*/) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // [NBUF][32 * 512]
   constexpr int kStage = 32 * 512;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1159,9 +1204,8 @@ __global__ __launch_bounds__(kMsQ * 64) __attribute__((amdgpu_waves_per_eu(4, 4)
       if (issued < ntiles) issue(issued++);
     const int n_first = issued;
     ms8h qh[8], ql[8];
-    float unscale;
-    ms_load_query_h(Q + (size_t)qi * q_len * kDim, q_len, live, r32, h, qh, ql, unscale);
-    unscale *= unscale_d;
+    ms_load_query_img(img_q, qi, r32, h, qh, ql);  // (a dead wave reads query 0's: its result is never stored)
+    const float unscale = unscale_q[qi] * unscale_d;
     // vmcnt counts in issue order: once the query loads (issued behind them) are in, so are this wave's pieces of the
     // first tiles — made explicit here, so that no later scheduling of the split arithmetic can move that point
     __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -1191,14 +1235,16 @@ __global__ __launch_bounds__(kMsQ * 64) __attribute__((amdgpu_waves_per_eu(4, 4)
       asm volatile("" ::: "memory");
       if (issued < ntiles) issue(issued++);
       const unsigned char* tile = ring + (done % NBUF) * kStage;
-      ms8h ah[8], al[8];
+      if (live) {  // wave-uniform: a wave without a query of this item (a document's last, partly filled item) only moves tiles
+        ms8h ah[8], al[8];
 #pragma unroll
-      for (int st = 0; st < 8; ++st) {
-        const unsigned char* fp = tile + foff[st];
-        ah[st] = *reinterpret_cast<const ms8h*>(fp);
-        al[st] = *reinterpret_cast<const ms8h*>(fp + 256);
+        for (int st = 0; st < 8; ++st) {
+          const unsigned char* fp = tile + foff[st];
+          ah[st] = *reinterpret_cast<const ms8h*>(fp);
+          al[st] = *reinterpret_cast<const ms8h*>(fp + 256);
+        }
+        ms_tile_h(ah, al, qh, ql, h, len - 32 * done, best);
       }
-      ms_tile_h(ah, al, qh, ql, h, len - 32 * done, best);
     }
     cur = nxt;
     nxt = nn;
@@ -1301,7 +1347,8 @@ size_t ms_workspace_bytes(const amdr_maxsim* h, int nq, int k, bool want_topk) {
   // [n_docs + 1], the item table (<= n_docs + pairs / 8 descriptors of 16 bytes)
   return 2 * rows + ((size_t)nq * ms_cand_cap(k) + 3 * (size_t)nq + 1) * sizeof(int) + 256 +
          ((size_t)nq * ms_cand_cap(k) + 4 * (size_t)h->n_docs + 8) * sizeof(int) +
-         ((size_t)h->n_docs + (size_t)nq * ms_cand_cap(k) / kMsQ + 8) * 16;
+         ((size_t)h->n_docs + (size_t)nq * ms_cand_cap(k) / kMsQ + 8) * 16 +
+         (size_t)nq * (32 * 512 + sizeof(float)) + 512;  // + the split image of the queries and their scales
 }
 
 int ms_run(amdr_maxsim* h, const float* Q_dev, int nq, int q_len, int k, float* full_dev, float* scores_dev,
@@ -1343,6 +1390,9 @@ int ms_run(amdr_maxsim* h, const float* Q_dev, int nq, int q_len, int k, float* 
     int* doff = dfill + h->n_docs;            // [n_docs + 1] first pair of a document
     int* ioff = doff + h->n_docs + 1;         // [n_docs + 1] first 8-query item of a document
     MsItem* items = reinterpret_cast<MsItem*>(((uintptr_t)(ioff + h->n_docs + 1) + 15) & ~(uintptr_t)15);
+    unsigned char* img_q = reinterpret_cast<unsigned char*>(
+        ((uintptr_t)(items + h->n_docs + (size_t)nq * cap / kMsQ + 8) + 255) & ~(uintptr_t)255);
+    float* unscale_q = reinterpret_cast<float*>(img_q + (size_t)nq * 32 * 512);
     const char* rs = getenv("AMDR_MAXSIM_RESCORE");  // "0": one wave per pair (the round-3 form; A/B, tests)
     const bool by_doc = !(rs && rs[0] == '0');
     if (by_doc) AMDR_HIP(hipMemsetAsync(dcnt, 0, 2 * (size_t)h->n_docs * sizeof(int), st));
@@ -1360,8 +1410,9 @@ int ms_run(amdr_maxsim* h, const float* Q_dev, int nq, int q_len, int k, float* 
                          doff, dfill, pairs);
       AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_rescore_ring_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    4 * 16384));
+      hipLaunchKernelGGL(ms_split_queries_kernel, dim3(nq), dim3(256), 0, st, Q_dev, q_len, img_q, unscale_q);
       hipLaunchKernelGGL((maxsim_rescore_ring_kernel<4>), dim3(2 * cus), dim3(kMsQ * 64), 4 * 16384, st, h->img, h->doc_ptr,
-                         (long)h->n_docs, Q_dev, q_len, unscale_d, items, ioff, pairs, exact);
+                         (long)h->n_docs, img_q, unscale_q, q_len, unscale_d, items, ioff, pairs, exact);
     } else {
       AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_rescore_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds));
       hipLaunchKernelGGL(maxsim_offsets_kernel, dim3(1), dim3(256), 0, st, cnt, nq, off);

@@ -41,6 +41,8 @@ from .rerankers import RerankerFactory, _to_doc_text
 
 logger = logging.getLogger("legalrag.retrieval.hybrid_retriever")
 
+_CHUNK_REPR: Dict[int, Any] = {}  # id(LawChunk) -> (the chunk, repr(chunk)): see HybridRetriever._hit_text
+
 CHANNELS = ("dense", "bm25", "colbert")
 
 
@@ -294,7 +296,10 @@ class HybridRetriever:
                 "channel": members, "channel_contrib": contrib, "rrf_norm": v[i_rn], "weighted_sum": v[i_ws],
                 "dense_norm": v[i_n[0]], "bm25_norm": v[i_n[1]], "colbert_norm": v[i_n[2]],
             }
-            out.append(RetrievalHit(chunk=chunk_of[i], score=v[i_s], rank=r + 1, source="retriever", score_breakdown=sb))
+            # model_construct: the fields come straight from the kernels' typed outputs and the store's own LawChunk
+            # objects — the validating constructor was a third of a batch's host time (validate_python per hit)
+            out.append(RetrievalHit.model_construct(chunk=chunk_of[i], score=v[i_s], rank=r + 1, source="retriever",
+                                                    score_breakdown=sb))
         return out
 
     def _eff_depth(self, top_k: int, who: str) -> int:
@@ -370,6 +375,25 @@ class HybridRetriever:
             int(bool(getattr(rcfg, "enable_graph", False))), int(self.colbert is not None), int(has_gpu))
         return fused[:top_k]
 
+    @staticmethod
+    def _hit_text(h: Any) -> str:
+        """str(hit) — what the reference's rerank stage hands to the cross-encoder (hybrid_retriever.py:343 passes the hit
+        objects, rerankers.py:78-86 stringifies them) — without pydantic walking the whole model per hit: the chunk's
+        repr (nearly all of the string: the law text) is cached per LawChunk object, the rest formatted field by field in
+        the schema's order.  Identical to str(h) (tests/test_host_logic.py; the reference-generated strings of
+        search_golden.json pin it end to end)."""
+        if type(h) is not RetrievalHit:
+            return _to_doc_text(h)
+        ck = h.chunk
+        ent = _CHUNK_REPR.get(id(ck))
+        if ent is None or ent[0] is not ck:
+            if len(_CHUNK_REPR) > 500_000:
+                _CHUNK_REPR.clear()
+            ent = _CHUNK_REPR[id(ck)] = (ck, repr(ck))
+        return (f"chunk={ent[1]} score={h.score!r} rank={h.rank!r} source={h.source!r} "
+                f"semantic_score={h.semantic_score!r} graph_depth={h.graph_depth!r} relations={h.relations!r} "
+                f"seed_article_id={h.seed_article_id!r} score_breakdown={h.score_breakdown!r}")
+
     def _rerank_stage(self, questions: Sequence[str], fused_lists: List[List[RetrievalHit]], llm: Any,
                       top_k: int) -> List[List[RetrievalHit]]:
         """hybrid_retriever.py:324-356 for one or many queries: the first rerank_top_n fused hits of each query are
@@ -392,7 +416,7 @@ class HybridRetriever:
         for qi, fused in enumerate(fused_lists):
             cand = fused[:rerank_top_n]
             if cand:
-                jobs.append((qi, factory.create(top_k=len(cand)), [_to_doc_text(h) for h in cand]))
+                jobs.append((qi, factory.create(top_k=len(cand)), [self._hit_text(h) for h in cand]))
         raws: Dict[int, List[float]] = {}
         by_model: Dict[int, List[int]] = {}
         for j, (_, rr, _) in enumerate(jobs):

@@ -260,3 +260,30 @@ def test_retrieve_response_matches_reference_route():
                                SimpleNamespace(retrieval=SimpleNamespace(top_k=10)), http_exception=None)
     with pytest.raises(service.ServiceError):
         route({})
+
+
+def test_hit_text_equals_pydantic_str():
+    """HybridRetriever._hit_text(h) == str(h) — the string the reference's rerank stage hands to the cross-encoder — for
+    hits of every shape the product builds (validated and model_construct-ed, with / without breakdowns, graph hits,
+    non-ASCII text, quotes and backslashes in the text)."""
+    from legal_rag_amd.retrieval.hybrid_retriever import HybridRetriever
+    from legal_rag_amd.schemas import LawChunk, RetrievalHit
+    chunks = [LawChunk(id=f"f::{i}", law_name="UCC", article_no=f"2-{i}", article_id=f"2-{i}",
+                       text=t, lang=lang, source=src, start_char=i, end_char=i + 9, chapter=ch)
+              for i, (t, lang, src, ch) in enumerate([
+                  ("A merchant's \"warranty\" \\ of fitness.\n(a) line", "en", "ucc_2.txt", None),
+                  ("认购书或者订购书等是否属于预约合同？", "zh", None, "第二章"),
+                  ("", None, None, None)])]
+    sb = {"fusion_method": "rrf_norm_blend", "rrf_k": 60, "alpha": 0.5, "channel_weights": {"dense": 0.6, "bm25": 0.4},
+          "channel": ["dense", "bm25"], "channel_contrib": {"dense": 0.3, "bm25": 0.1, "colbert": 0.0}, "rrf_norm": 1.0,
+          "weighted_sum": 0.4, "dense_norm": 0.5, "bm25_norm": 0.25, "colbert_norm": 0.0, "zh_exact": False}
+    hits = [RetrievalHit(chunk=chunks[0], score=0.8, rank=1, score_breakdown=sb),
+            RetrievalHit.model_construct(chunk=chunks[1], score=1e-17, rank=2, source="retriever", score_breakdown=dict(sb)),
+            RetrievalHit(chunk=chunks[2], score=float("inf"), rank=None),
+            RetrievalHit(chunk=chunks[0], score=0.25, rank=4, source="graph", graph_depth=2, relations=["cites", "x"],
+                         seed_article_id="2-1", semantic_score=0.33, score_breakdown={"graph": {"decay": 0.5}}),
+            RetrievalHit(chunk=chunks[1], score=-0.0, rank=5, source="rerank",
+                         score_breakdown={"rerank_raw": 0.1, "rerank_norm": 1.0, "rerank_beta": 0.35})]
+    for h in hits * 2:  # second pass: the cached chunk reprs
+        assert HybridRetriever._hit_text(h) == str(h)
+    assert HybridRetriever._hit_text("plain") == "plain" and HybridRetriever._hit_text({"text": "t"}) == "t"
