@@ -676,7 +676,8 @@ def scan_algorithmic_bytes(plan, n, d, B, k):
     hi = kernel == "dense_hi_tilemax_kernel"  # fp16 first pass: <= 64 queries per scan
     per_scan = int(plan.split("queries_per_launch=")[1].split()[0]) if "queries_per_launch=" in plan else B
     if hi:  # the scan emits only the maxima that reach the sample's threshold (~kc x stride per query): no per-tile output
-        return kernel, hi, per_scan, float(n) * d * 4 + per_scan * d * 4
+        scans = int(plan.split("scans_per_launch=")[1].split()[0]) if "scans_per_launch=" in plan else 1
+        return kernel, hi, per_scan, (float(n) * d * 4) * scans + per_scan * d * 4  # one launch walks `scans` query tiles
     nbytes = float(n) * d * 4 + per_scan * d * 4 + (
         (float(n) / 32 * per_scan * 4 if two_level else float(n) * per_scan * 4) if batched else B * k * 8)
     return kernel, hi, per_scan, nbytes
@@ -809,7 +810,8 @@ def run_shard8_proxy(torch, device, n=1_250_000, d=768, k=10, steps=30):
         # the exchange's two launches for this batch (one channel) at world = 1
         xc = {}
         ex_us = event_ms(torch, lambda: sharding.exchange_topk([(s, i)], 0, cache=xc), 50) * 1e3
-        bytes_scan = float(n) * d * 4 * launches / steps
+        scans = int(plan.split("scans_per_launch=")[1].split()[0]) if "scans_per_launch=" in plan else 1
+        bytes_scan = float(n) * d * 4 * scans * launches / steps
         out["searches"].append({
             "queries": B, "plan": plan, "scan_launches_per_search": launches / steps, "scan_ms_per_search": scan_per_search,
             "stream_ms_per_search": per_search_ms, "tail_us_behind_the_scans": (per_search_ms - scan_per_search) * 1e3,

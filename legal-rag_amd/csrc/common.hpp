@@ -127,7 +127,7 @@ int dense_hi2_launch_sample(const float* X, long n, int d, const float* Q, int n
 int dense_hi2_launch_tau(const float* MT, long n, int d, int nq, int qtiles, int kc, float* tau, unsigned int* qcount,
                          int* flag, unsigned int* stats, hipStream_t st);
 int dense_hi2_launch_emit(const float* X, long n, int d, const float* Q, int nq, const float* tau, void* qlist,
-                          unsigned int* qcount, size_t qcap, hipStream_t st, float x_scale);
+                          unsigned int* qcount, size_t qcap, hipStream_t st, float x_scale, int qtiles);
 int dense_hi2_launch_select(const void* qlist, const unsigned int* qcount, size_t qcap, int m, int kc, int k, const float* Q,
                             int d, float row_norm_max, float x_scale, long n_tiles, int* list, int* count, int* unres,
                             int* flag, unsigned int* unresolved, hipStream_t st);

@@ -861,16 +861,13 @@ int hi2_pass(amdr_dense* h, int ws, const float* Qc, int m, int k, int kc, float
   float* tau = reinterpret_cast<float*>(ax + p.off_tau);
   unsigned int* qcount = reinterpret_cast<unsigned int*>(ax + p.off_qcount);
   unsigned int* stats = h->stats.as<unsigned int>();
-  const int qt = dense_hi_max_queries(h->d);
   int rc;
   if ((rc = dense_hi2_launch_sample(h->X, (long)h->n, h->d, Qc, m, p.qtiles, MT, st, h->x_scale))) return rc;
   if ((rc = dense_hi2_launch_tau(MT, (long)h->n, h->d, m, p.qtiles, kc, tau, qcount, flag, stats, st))) return rc;
-  for (int y = 0; y < p.qtiles; ++y) {
-    const int q0 = y * qt, mq = m - q0 < qt ? m - q0 : qt;
+  {  // the scan: ONE launch over all query tiles of the pass (the launch the profiling events bracket)
     const bool prof = h->prof_on && (size_t)(h->prof_used + 2) <= h->prof_ev.size();
     if (prof) AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
-    if ((rc = dense_hi2_launch_emit(h->X, (long)h->n, h->d, Qc + (size_t)q0 * h->d, mq, tau + q0, qlist + (size_t)q0 * p.qcap,
-                                    qcount + q0, p.qcap, st, h->x_scale)))
+    if ((rc = dense_hi2_launch_emit(h->X, (long)h->n, h->d, Qc, m, tau, qlist, qcount, p.qcap, st, h->x_scale, p.qtiles)))
       return rc;
     if (prof) {
       AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
@@ -1313,11 +1310,11 @@ int amdr_dense_plan_info(const amdr_dense_t* h, int32_t nq, int32_t k, char* buf
     Hi2Plan p;
     hi2_plan(h, m, k, kc, &p);
     snprintf(buf, buf_len,
-             "dense_hi_tilemax_kernel fp16 first pass queries_per_launch=%d (%d per pass, one tail): per-query lists of the "
+             "dense_hi_tilemax_kernel fp16 first pass queries_per_launch=%d scans_per_launch=%d (%d per scan, one tail): per-query lists of the "
              "approximate tile maxima above a sampled threshold (every %ld-th tile, width level %d) -> top-%d + rounding-bound "
              "check + exact re-scoring of each query's tiles at or above its cut (<= %d each) + top-k: 4 launches behind the "
              "scan(s), the exact first pass behind a device flag in 2",
-             m < dense_hi_max_queries(h->d) ? m : dense_hi_max_queries(h->d), m,
+             m, p.qtiles, m < dense_hi_max_queries(h->d) ? m : dense_hi_max_queries(h->d),
              dense_hi2_sample_stride((long)h->n, p.qtiles), hi_level_of(h), kc, kc);
     return AMDR_OK;
   }

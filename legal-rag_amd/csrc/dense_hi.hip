@@ -67,16 +67,15 @@ struct HiEmit {
   C32* qlist;
   unsigned int* qcount;
   unsigned int qcap;
+  int n_qtiles;  // > 1: the launch scans the matrix once per query tile (tau / qlist / qcount of tile y at y x the tile size)
 };
 constexpr int kHiQShift = 26;  // tiles < 2^26
 
 template <int D64, bool EMIT>  // d / 64
-__global__ __launch_bounds__(kHiWaves * 64) void dense_hi_tilemax_kernel(const float* __restrict__ X, long n,
-                                                                         const float* __restrict__ Q, int nq,
-                                                                         float* __restrict__ MT /*[items][cols]*/,
-                                                                         int cols, float x_scale, long tile_stride,
-                                                                         long n_items, HiEmit em) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void hi_tilemax_pass(const float* __restrict__ X, long n, const float* __restrict__ Q, int nq,
+                                                float* __restrict__ MT /*[items][cols]*/, int cols, float x_scale,
+                                                long tile_stride, long n_items, const HiEmit& em, unsigned char* smem,
+                                                int qoff /* first query of this pass in tau / qlist / qcount */) {
   constexpr int d = D64 * 64;
   constexpr int NCH = D64;
   constexpr int QT = hi_query_tile(d);  // queries of the LDS tile: 64, or 48 at d = 1 024 (96 KiB either way at the widest)
@@ -192,7 +191,9 @@ __global__ __launch_bounds__(kHiWaves * 64) void dense_hi_tilemax_kernel(const f
   // EMIT: the wave's staging buffer and its fill (wave-uniform), the lane's threshold
   C32* wbuf = reinterpret_cast<C32*>(smem + QT * d * 2 + kHiWaves * kHiStageBytes) + (size_t)wave * (EMIT ? em.wbuf : 0);
   int wcnt = 0;
-  const float tau = (EMIT && lane < nq) ? em.tau[(size_t)lane * em.tau_stride] : 0.f;
+  const float tau = (EMIT && lane < nq) ? em.tau[(size_t)(qoff + lane) * em.tau_stride] : 0.f;
+  unsigned int* const qcount = EMIT ? em.qcount + qoff : nullptr;
+  C32* const qlist = EMIT ? em.qlist + (size_t)qoff * em.qcap : nullptr;
   const bool perq = EMIT && em.qcount != nullptr;
   auto flush = [&]() {
     if (perq) {  // a full buffer in the middle of a run (rare): one returning atomic per entry
@@ -201,8 +202,8 @@ __global__ __launch_bounds__(kHiWaves * 64) void dense_hi_tilemax_kernel(const f
         const unsigned int id = 0xffffffffu - (unsigned int)c.c;
         const unsigned int q = id >> kHiQShift;
         c.c = (c.c & 0xffffffff00000000ull) | (u64)(0xffffffffu - (id & ((1u << kHiQShift) - 1u)));
-        const unsigned int pos = atomicAdd(em.qcount + q, 1u);
-        if (pos < em.qcap) em.qlist[(size_t)q * em.qcap + pos] = c;
+        const unsigned int pos = atomicAdd(qcount + q, 1u);
+        if (pos < em.qcap) qlist[(size_t)q * em.qcap + pos] = c;
       }
     } else {
       unsigned int base = 0;
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(kHiWaves * 64) void dense_hi_tilemax_kernel(const f
     __syncthreads();
     if (wave == 0) {
       const int c = bh[lane];
-      bb[lane] = c > 0 ? atomicAdd(em.qcount + lane, (unsigned int)c) : 0u;
+      bb[lane] = c > 0 ? atomicAdd(qcount + lane, (unsigned int)c) : 0u;
     }
     __syncthreads();
 #pragma unroll
@@ -343,9 +344,31 @@ __global__ __launch_bounds__(kHiWaves * 64) void dense_hi_tilemax_kernel(const f
         const unsigned int id = 0xffffffffu - (unsigned int)c.c;
         c.c = (c.c & 0xffffffff00000000ull) | (u64)(0xffffffffu - (id & ((1u << kHiQShift) - 1u)));
         const unsigned int dst = bb[qq[j]] + (unsigned int)pos[j];
-        if (dst < em.qcap) em.qlist[(size_t)qq[j] * em.qcap + dst] = c;
+        if (dst < em.qcap) qlist[(size_t)qq[j] * em.qcap + dst] = c;
       }
     }
+  }
+}
+
+// The kernel: one pass per query tile.  The scan of a search with several query tiles (round 4: up to four per tail) is ONE
+// launch that walks the tiles — convert tile y, scan, flush, next tile — instead of one launch per tile: no drain and
+// refill of the chip between the scans (10 us each) and the waves' uneven ends overlap with the next tile's start.
+template <int D64, bool EMIT>
+__global__ __launch_bounds__(kHiWaves * 64) void dense_hi_tilemax_kernel(const float* __restrict__ X, long n,
+                                                                         const float* __restrict__ Q, int nq,
+                                                                         float* __restrict__ MT /*[items][cols]*/,
+                                                                         int cols, float x_scale, long tile_stride,
+                                                                         long n_items, HiEmit em) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int QT = hi_query_tile(D64 * 64);
+  const int tiles = (EMIT && em.n_qtiles > 1) ? em.n_qtiles : 1;
+#pragma unroll 1
+  for (int y = 0; y < tiles; ++y) {  // (one call site: a second inlined copy of the pass spilled registers)
+    int nq_y = nq - y * QT;
+    nq_y = nq_y > QT ? QT : nq_y;
+    hi_tilemax_pass<D64, EMIT>(X, n, Q + (size_t)y * QT * (D64 * 64), nq_y, MT, cols, x_scale, tile_stride, n_items, em, smem,
+                               y * QT);
+    if (y + 1 < tiles) __syncthreads();  // every wave is done with this tile's queries and lists before the next is converted
   }
 }
 
@@ -531,8 +554,9 @@ static int launch_hi(const float* X, long n, const float* Q, int nq, int grid, f
 
 template <bool EMIT>
 static int launch_hi_d(const float* X, long n, int d, const float* Q, int nq, float* MT, float x_scale, long tile_stride,
-                       const HiEmit& em, hipStream_t st, int grid_y = 1) {
-  if (!dense_hi_supported(d) || nq < 1 || nq > grid_y * hi_query_tile(d)) return fail(AMDR_EINVAL, "dense (fp16 first pass): d=%d nq=%d", d, nq);
+                       const HiEmit& em, hipStream_t st, int grid_y = 1, int scan_tiles = 1) {
+  if (!dense_hi_supported(d) || nq < 1 || nq > grid_y * scan_tiles * hi_query_tile(d))
+    return fail(AMDR_EINVAL, "dense (fp16 first pass): d=%d nq=%d", d, nq);
   // one persistent block per CU (the query tile fills most of its LDS)
   int dev = 0, cus = 256;
   AMDR_HIP(hipGetDevice(&dev));
@@ -732,14 +756,16 @@ __global__ __launch_bounds__(256) void dense_hi_select_kernel(const C32* __restr
   // (two or three per wave, then three merges) were 25 of this kernel's 32 us.  Mass ties at the cut (> 64 survivors),
   // long lists and wide cuts take the staged selector on all four waves.
   int got = -1;
-  if (n <= 2048u && kc1 <= 64) {  // block-uniform
+  if (n <= 4096u && kc1 <= 64) {  // block-uniform
     if (wave != 0) return;
     if (n <= 512u)
       got = select_list<8>(src, n, kc1, lane, tk.buf);
     else if (n <= 1024u)
       got = select_list<16>(src, n, kc1, lane, tk.buf);
-    else
+    else if (n <= 2048u)
       got = select_list<32>(src, n, kc1, lane, tk.buf);
+    else  // (a four-tile pass samples every 77th tile of a 1.25 M-row shard: ~2 500 entries per query)
+      got = select_list<64>(src, n, kc1, lane, tk.buf);
     if (got >= 0) {
       tk.cnt = got;
     } else {  // mass ties: this wave alone, staged
@@ -914,10 +940,10 @@ int dense_hi2_launch_tau(const float* MT, long n, int d, int nq, int qtiles, int
 }
 // the scan of ONE query tile: maxima >= tau[q] into the per-query lists
 int dense_hi2_launch_emit(const float* X, long n, int d, const float* Q, int nq, const float* tau, void* qlist,
-                          unsigned int* qcount, size_t qcap, hipStream_t st, float x_scale) {
+                          unsigned int* qcount, size_t qcap, hipStream_t st, float x_scale, int qtiles) {
   if ((n + 31) / 32 >= (1l << kHiQShift)) return fail(AMDR_EINVAL, "dense (fp16 first pass): too many tiles");
-  HiEmit em{tau, 1, nullptr, nullptr, 0u, hi_wbuf_entries(d), (C32*)qlist, qcount, (unsigned int)qcap};
-  return launch_hi_d<true>(X, n, d, Q, nq, nullptr, x_scale, 1, em, st);
+  HiEmit em{tau, 1, nullptr, nullptr, 0u, hi_wbuf_entries(d), (C32*)qlist, qcount, (unsigned int)qcap, qtiles};
+  return launch_hi_d<true>(X, n, d, Q, nq, nullptr, x_scale, 1, em, st, 1, qtiles);
 }
 int dense_hi2_launch_select(const void* qlist, const unsigned int* qcount, size_t qcap, int m, int kc, int k, const float* Q,
                             int d, float row_norm_max, float x_scale, long n_tiles, int* list, int* count, int* unres,
