@@ -864,14 +864,22 @@ int hi2_pass(amdr_dense* h, int ws, const float* Qc, int m, int k, int kc, float
   int rc;
   if ((rc = dense_hi2_launch_sample(h->X, (long)h->n, h->d, Qc, m, p.qtiles, MT, st, h->x_scale))) return rc;
   if ((rc = dense_hi2_launch_tau(MT, (long)h->n, h->d, m, p.qtiles, kc, tau, qcount, flag, stats, st))) return rc;
-  {  // the scan: ONE launch over all query tiles of the pass (the launch the profiling events bracket)
-    const bool prof = h->prof_on && (size_t)(h->prof_used + 2) <= h->prof_ev.size();
-    if (prof) AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
-    if ((rc = dense_hi2_launch_emit(h->X, (long)h->n, h->d, Qc, m, tau, qlist, qcount, p.qcap, st, h->x_scale, p.qtiles)))
-      return rc;
-    if (prof) {
-      AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
-      h->prof_used += 2;
+  {  // the scan: ONE launch over all query tiles of the pass (the launch the profiling events bracket);
+     // AMDR_DENSE_HI_SCANS=split: one launch per query tile (A/B, tests)
+    const char* sp = getenv("AMDR_DENSE_HI_SCANS");
+    const bool split = sp && sp[0] == 's';
+    const int qt = dense_hi_max_queries(h->d);
+    for (int y = 0; y < (split ? p.qtiles : 1); ++y) {
+      const int q0 = y * qt, mq = split ? (m - q0 < qt ? m - q0 : qt) : m;
+      const bool prof = h->prof_on && (size_t)(h->prof_used + 2) <= h->prof_ev.size();
+      if (prof) AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
+      if ((rc = dense_hi2_launch_emit(h->X, (long)h->n, h->d, Qc + (size_t)q0 * h->d, mq, tau + q0, qlist + (size_t)q0 * p.qcap,
+                                      qcount + q0, p.qcap, st, h->x_scale, split ? 1 : p.qtiles)))
+        return rc;
+      if (prof) {
+        AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
+        h->prof_used += 2;
+      }
     }
   }
   h->hi_queries += m;

@@ -364,8 +364,11 @@ __global__ __launch_bounds__(kHiWaves * 64) void dense_hi_tilemax_kernel(const f
   const int tiles = (EMIT && em.n_qtiles > 1) ? em.n_qtiles : 1;
 #pragma unroll 1
   for (int y = 0; y < tiles; ++y) {  // (one call site: a second inlined copy of the pass spilled registers)
-    int nq_y = nq - y * QT;
-    nq_y = nq_y > QT ? QT : nq_y;
+    int nq_y = nq;  // (the SAMPLE of a multi-tile search runs one tile per block row: it takes its share of nq itself)
+    if (tiles > 1) {
+      nq_y = nq - y * QT;
+      nq_y = nq_y > QT ? QT : nq_y;
+    }
     hi_tilemax_pass<D64, EMIT>(X, n, Q + (size_t)y * QT * (D64 * 64), nq_y, MT, cols, x_scale, tile_stride, n_items, em, smem,
                                y * QT);
     if (y + 1 < tiles) __syncthreads();  // every wave is done with this tile's queries and lists before the next is converted

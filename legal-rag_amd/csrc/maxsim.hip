@@ -869,18 +869,58 @@ __global__ __launch_bounds__(kMsQ2 * 64) __attribute__((amdgpu_waves_per_eu(3, 3
   }
 }
 
+// One wave splits one query into the [hi | lo] image of the re-scoring pass (512 B per token row, 32 rows, rows past q_len
+// zero) and stores its power-of-two unscale — the scale rule and ms_split of ms_load_query_h: identical fragments.  The
+// re-scoring pass takes a query's fragments for every (document, query) item it serves, 15 k times per UCC-en batch:
+// splitting them in the scoring wave each time cost ~500 vector instructions per item and wave.
+__device__ __forceinline__ void ms_split_query_wave(const float* __restrict__ Qq, int q_len, int lane,
+                                                    unsigned char* __restrict__ img, float* __restrict__ unscale) {
+  float m = 0.f;
+  for (int i = lane; i < q_len * kDim; i += 64) m = fmaxf(m, fabsf(Qq[i]));
+#pragma unroll
+  for (int sft = 1; sft < 64; sft <<= 1) m = fmaxf(m, __shfl_xor(m, sft));
+  int e = 0;
+  if (m > 0.f && m <= FLT_MAX) (void)frexpf(m, &e);
+  const float sc = ldexpf(1.f, -e);
+  if (lane == 0) *unscale = ldexpf(1.f, e);
+  for (int g = lane; g < 32 * 16; g += 64) {  // (token row, group of 8 components)
+    const int row = g >> 4, grp = g & 15;
+    float x[8];
+    if (row < q_len) {
+      const ms4f v0 = *reinterpret_cast<const ms4f*>(Qq + (size_t)row * kDim + 8 * grp);
+      const ms4f v1 = *reinterpret_cast<const ms4f*>(Qq + (size_t)row * kDim + 8 * grp + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[j] = v0[j], x[4 + j] = v1[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = 0.f;
+    }
+    ms8h hi, lo;
+    ms_split(x, sc, hi, lo);
+    unsigned char* dst = img + (size_t)row * 512 + 16 * grp;
+    *reinterpret_cast<ms8h*>(dst) = hi;
+    *reinterpret_cast<ms8h*>(dst + 256) = lo;
+  }
+}
+
 // Between the passes, one wave per query: T = the k-th best first-pass score, eps from the query's token norms, the
 // list of documents with a first-pass score >= T - 2 eps (ascending ids, at most cap; more -> overflow), and the
 // re-scored row initialised to "not a candidate".
-__global__ __launch_bounds__(64) void maxsim_select_kernel(const float* __restrict__ approx, long n_docs,
+__global__ __launch_bounds__(128) void maxsim_select_kernel(const float* __restrict__ approx, long n_docs,
                                                            const float* __restrict__ Q, int q_len, int k, int cap_sel,
                                                            float d_norm_max, float unscale_d, int cap,
                                                            float* __restrict__ exact /*[nq, n_docs]*/,
                                                            int* __restrict__ cand /*[nq, cap]*/, int* __restrict__ cnt,
-                                                           int* __restrict__ overflow, int* __restrict__ dcnt) {
+                                                           int* __restrict__ overflow, int* __restrict__ dcnt,
+                                                           unsigned char* __restrict__ img_q,
+                                                           float* __restrict__ unscale_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   C32* buf = reinterpret_cast<C32*>(smem);
-  const int lane = threadIdx.x, q = blockIdx.x;
+  const int lane = threadIdx.x & 63, q = blockIdx.x;
+  if (threadIdx.x >= 64) {  // round 4: a second wave of the block splits the query for the re-scoring pass meanwhile
+    ms_split_query_wave(Q + (size_t)q * q_len * kDim, q_len, lane, img_q + (size_t)q * 32 * 512, unscale_out + q);
+    return;
+  }
   const float* row = approx + (size_t)q * n_docs;
   WaveTopK<C32> tk;
   tk.init(buf, cap_sel, k);
@@ -1043,40 +1083,6 @@ __global__ __launch_bounds__(256) void maxsim_rescore_kernel(const unsigned char
   }
 }
 
-// The queries of a batch split ONCE into the [hi | lo] image the document tokens have (512 B per token row, 32 rows per
-// query, rows past q_len zero) + the query's power-of-two unscale: the re-scoring pass takes a query's fragments for
-// every (document, query) item it serves — 15 k times per UCC-en batch — and splitting them in the scoring wave each time
-// (64 loads' worth of fp32 -> 2 x fp16 arithmetic, ~500 vector instructions) cost as much as the item's MFMAs.  Same
-// scale rule and the same ms_split as ms_load_query_h: identical fragments.
-__global__ __launch_bounds__(256) void ms_split_queries_kernel(const float* __restrict__ Q, int q_len,
-                                                               unsigned char* __restrict__ img_q,
-                                                               float* __restrict__ unscale_q) {
-  __shared__ float red[4];
-  const int q = blockIdx.x, tid = threadIdx.x;
-  const float* Qq = Q + (size_t)q * q_len * kDim;
-  float m = 0.f;
-  for (int i = tid; i < q_len * kDim; i += 256) m = fmaxf(m, fabsf(Qq[i]));
-#pragma unroll
-  for (int sft = 1; sft < 64; sft <<= 1) m = fmaxf(m, __shfl_xor(m, sft));
-  if ((tid & 63) == 0) red[tid >> 6] = m;
-  __syncthreads();
-  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  int e = 0;
-  if (m > 0.f && m <= FLT_MAX) (void)frexpf(m, &e);
-  const float sc = ldexpf(1.f, -e);
-  if (tid == 0) unscale_q[q] = ldexpf(1.f, e);
-  for (int g = tid; g < 32 * 16; g += 256) {  // (token row, group of 8 components)
-    const int row = g >> 4, grp = g & 15;
-    float x[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = row < q_len ? Qq[(size_t)row * kDim + 8 * grp + j] : 0.f;
-    ms8h hi, lo;
-    ms_split(x, sc, hi, lo);
-    unsigned char* dst = img_q + ((size_t)q * 32 + row) * 512 + 16 * grp;
-    *reinterpret_cast<ms8h*>(dst) = hi;
-    *reinterpret_cast<ms8h*>(dst + 256) = lo;
-  }
-}
 __device__ __forceinline__ void ms_load_query_img(const unsigned char* __restrict__ img_q, int qi, int r32, int h,
                                                   ms8h (&qh)[8], ms8h (&ql)[8]) {
   const unsigned char* p = img_q + ((size_t)qi * 32 + r32) * 512 + 16 * h;
@@ -1097,10 +1103,12 @@ __device__ __forceinline__ void ms_load_query_img(const unsigned char* __restric
 //   maxsim_doc_offsets_kernel   exclusive prefix sums over the documents: pairs (doff) and 8-query items (ioff)
 //   maxsim_pairs_fill_kernel    pairs[doff[doc] + slot] = query
 //   maxsim_rescore_ring_kernel  persistent blocks of 8 waves walk the items
-struct MsItem {  // one unit of the re-scoring pass: a document and up to 8 of its queries
-  int doc, p0, cnt, pad;
+struct MsItem {  // one unit of the re-scoring pass: a document (its token range) and up to 8 of its queries
+  int doc, p0, cnt, len;
+  long long t_lo, pad;
 };
 __global__ __launch_bounds__(256) void maxsim_doc_offsets_kernel(const int* __restrict__ dcnt, long n_docs,
+                                                                 const long long* __restrict__ doc_ptr,
                                                                  int* __restrict__ doff, int* __restrict__ ioff,
                                                                  MsItem* __restrict__ items) {
   __shared__ int part[2][256];
@@ -1126,8 +1134,10 @@ __global__ __launch_bounds__(256) void maxsim_doc_offsets_kernel(const int* __re
       ioff[i] = i0;
       // the item table: the re-scoring blocks read ONE 16-byte descriptor per item instead of searching the offsets (ten
       // dependent loads per item and wave)
+      const long long t_lo = it ? doc_ptr[i] : 0;
+      const int len = it ? (int)(doc_ptr[i + 1] - t_lo) : 0;
       for (int c = 0; c < it; ++c)
-        items[i0 + c] = MsItem{(int)i, p0 + c * kMsQ, v - c * kMsQ < kMsQ ? v - c * kMsQ : kMsQ, 0};
+        items[i0 + c] = MsItem{(int)i, p0 + c * kMsQ, v - c * kMsQ < kMsQ ? v - c * kMsQ : kMsQ, len, t_lo, 0};
     }
     carry_p += part[0][255];
     carry_i += part[1][255];
@@ -1152,10 +1162,9 @@ __global__ __launch_bounds__(256) void maxsim_pairs_fill_kernel(const int* __res
 
 template <int NBUF>
 __global__ __launch_bounds__(kMsQ * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void maxsim_rescore_ring_kernel(
-    const unsigned char* __restrict__ img, const long long* __restrict__ doc_ptr, long n_docs,
-    const unsigned char* __restrict__ img_q, const float* __restrict__ unscale_q, int q_len, float unscale_d,
-    const MsItem* __restrict__ item_tab, const int* __restrict__ ioff, const int* __restrict__ pairs,
-    float* __restrict__ exact /*[nq, n_docs]*/) {
+    const unsigned char* __restrict__ img, long n_docs, const unsigned char* __restrict__ img_q,
+    const float* __restrict__ unscale_q, int q_len, float unscale_d, const MsItem* __restrict__ item_tab,
+    const int* __restrict__ ioff, const int* __restrict__ pairs, float* __restrict__ exact /*[nq, n_docs]*/) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // [NBUF][32 * 512]
   constexpr int kStage = 32 * 512;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1171,55 +1180,53 @@ __global__ __launch_bounds__(kMsQ * 64) __attribute__((amdgpu_waves_per_eu(4, 4)
 #pragma unroll
   for (int st = 0; st < 8; ++st) foff[st] = ms_tile_off(r32, 2 * st + h);
   const int items = ioff[n_docs];
-  // Two items of look-ahead so that no item waits for a chain of dependent loads: the DESCRIPTOR of item i + 2 and the
-  // scalars of item i + 1 (its query of this wave, its document's extent — they need i + 1's descriptor, which is in
-  // registers by then) are requested while item i is multiplied.
   const int stride = (int)gridDim.x;
-  auto desc_of = [&](int it) { return it < items ? item_tab[it] : MsItem{0, 0, 0, 0}; };
-  MsItem cur = desc_of(blockIdx.x), nxt = desc_of(blockIdx.x + stride);
-  int qi_c = wave < cur.cnt ? pairs[cur.p0 + wave] : 0;
-  long tlo_c = doc_ptr[cur.doc], thi_c = doc_ptr[cur.doc + 1];
+  auto desc_of = [&](int it) { return it < items ? item_tab[it] : MsItem{0, 0, 0, 0, 0, 0}; };
+  // The block's items (blockIdx.x, + gridDim.x, ...) are ONE stream of tiles through the ring: the producer cursor runs up
+  // to NBUF - 1 tiles ahead of the consumer ACROSS item boundaries (a document has ~5 tiles: restarting the ring per item
+  // exposed a memory latency per item and left the ring mostly empty).  Consumer look-ahead: the descriptor of the item
+  // after next and this wave's query of the next item are requested while the current item is multiplied.
+  MsItem c_cur = desc_of(blockIdx.x), c_nxt = desc_of(blockIdx.x + stride);
+  int qi_c = wave < c_cur.cnt ? pairs[c_cur.p0 + wave] : 0;
+  MsItem p_cur = c_cur, p_nxt = c_nxt;
+  int p_item = blockIdx.x, p_tile = 0;
+  int issued = 0, done = 0;
+  auto produce = [&]() {
+    while (p_item < items && p_tile >= ((p_cur.len + 31) >> 5)) {  // the producer moves on to its next item
+      p_item += stride;
+      p_cur = p_nxt;
+      p_nxt = desc_of(p_item + stride);
+      p_tile = 0;
+    }
+    if (p_item >= items) return;
+    const unsigned char* src = img + (size_t)(p_cur.t_lo + 32 * p_tile) * 512;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      __builtin_amdgcn_global_load_lds(AMDR_MS_GPTR(src + poff[u]),
+                                       AMDR_MS_LPTR(ring + (issued % NBUF) * kStage + (2 * wave + u) * 1024), 16, 0, 0);
+    ++issued;
+    ++p_tile;
+  };
+#pragma unroll
+  for (int i = 0; i < NBUF - 1; ++i) produce();
   for (int item = blockIdx.x; item < items; item += stride) {
-    const long doc = cur.doc;
-    const bool live = wave < cur.cnt;
-    const int qi = qi_c;
-    const long t_lo = tlo_c;
-    const int len = (int)(thi_c - tlo_c);
-    const int ntiles = (len + 31) >> 5;
-    // every wave has read the last tile of the previous item before its stage is refilled
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    int issued = 0;
-    auto issue = [&](int tile) {
-      const unsigned char* src = img + (size_t)(t_lo + 32 * tile) * 512;
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-        __builtin_amdgcn_global_load_lds(AMDR_MS_GPTR(src + poff[u]),
-                                         AMDR_MS_LPTR(ring + (tile % NBUF) * kStage + (2 * wave + u) * 1024), 16, 0, 0);
-    };
-    // the first tiles are on their way BEFORE the query fragments are fetched and split: the two latencies overlap
-#pragma unroll
-    for (int i = 0; i < NBUF - 1; ++i)
-      if (issued < ntiles) issue(issued++);
-    const int n_first = issued;
+    const bool live = wave < c_cur.cnt;
+    const int qi = qi_c, len = c_cur.len, ntiles = (c_cur.len + 31) >> 5;
     ms8h qh[8], ql[8];
     ms_load_query_img(img_q, qi, r32, h, qh, ql);  // (a dead wave reads query 0's: its result is never stored)
     const float unscale = unscale_q[qi] * unscale_d;
-    // vmcnt counts in issue order: once the query loads (issued behind them) are in, so are this wave's pieces of the
-    // first tiles — made explicit here, so that no later scheduling of the split arithmetic can move that point
+    // vmcnt counts in issue order: with the fragments (the youngest requests) in, every DMA issued so far has landed
     __builtin_amdgcn_s_waitcnt(0x0F70);
     asm volatile("" ::: "memory");
-    // look-ahead (see above): scalars of the next item, descriptor of the one after
+    const int safe = issued;  // tiles below this index need no further wait by this wave
     const MsItem nn = desc_of(item + 2 * stride);
-    const int qi_n = wave < nxt.cnt ? pairs[nxt.p0 + wave] : 0;
-    const long tlo_n = doc_ptr[nxt.doc], thi_n = doc_ptr[nxt.doc + 1];
+    const int qi_n = wave < c_nxt.cnt ? pairs[c_nxt.p0 + wave] : 0;
     float best = -FLT_MAX;
-    for (int done = 0; done < ntiles; ++done) {
+    for (int t = 0; t < ntiles; ++t) {
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the fragment reads of the previous tile
-      if (done >= n_first) {
-        // a tile issued inside this loop: landed once at most 2 x (tiles issued behind it) DMAs are outstanding (the
-        // look-ahead loads above are older than every DMA of the loop)
+      if (done >= safe) {
+        // this wave's pieces of tile `done`: landed once at most 2 x (tiles issued behind it) requests are outstanding
+        // (other loads issued meanwhile only make the wait stricter)
         const int behind = issued - done - 1;
         if (behind >= 3) {
           __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(6)
@@ -1231,11 +1238,11 @@ __global__ __launch_bounds__(kMsQ * 64) __attribute__((amdgpu_waves_per_eu(4, 4)
           __builtin_amdgcn_s_waitcnt(0x0F70);
         }
       }
-      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();  // everybody's pieces of tile `done` are in; tile done - 1 has been read by all
       asm volatile("" ::: "memory");
-      if (issued < ntiles) issue(issued++);
-      const unsigned char* tile = ring + (done % NBUF) * kStage;
+      produce();                     // into the stage of tile done - 1
       if (live) {  // wave-uniform: a wave without a query of this item (a document's last, partly filled item) only moves tiles
+        const unsigned char* tile = ring + (done % NBUF) * kStage;
         ms8h ah[8], al[8];
 #pragma unroll
         for (int st = 0; st < 8; ++st) {
@@ -1243,16 +1250,15 @@ __global__ __launch_bounds__(kMsQ * 64) __attribute__((amdgpu_waves_per_eu(4, 4)
           ah[st] = *reinterpret_cast<const ms8h*>(fp);
           al[st] = *reinterpret_cast<const ms8h*>(fp + 256);
         }
-        ms_tile_h(ah, al, qh, ql, h, len - 32 * done, best);
+        ms_tile_h(ah, al, qh, ql, h, len - 32 * t, best);
       }
+      ++done;
     }
-    cur = nxt;
-    nxt = nn;
-    qi_c = qi_n;
-    tlo_c = tlo_n;
-    thi_c = thi_n;
     const float total = ms_finish_h(best, r32, h, q_len, unscale);
-    if (live && lane == 0) exact[(size_t)qi * n_docs + doc] = total;
+    if (live && lane == 0) exact[(size_t)qi * n_docs + c_cur.doc] = total;
+    c_cur = c_nxt;
+    c_nxt = nn;
+    qi_c = qi_n;
   }
 }
 
@@ -1347,7 +1353,7 @@ size_t ms_workspace_bytes(const amdr_maxsim* h, int nq, int k, bool want_topk) {
   // [n_docs + 1], the item table (<= n_docs + pairs / 8 descriptors of 16 bytes)
   return 2 * rows + ((size_t)nq * ms_cand_cap(k) + 3 * (size_t)nq + 1) * sizeof(int) + 256 +
          ((size_t)nq * ms_cand_cap(k) + 4 * (size_t)h->n_docs + 8) * sizeof(int) +
-         ((size_t)h->n_docs + (size_t)nq * ms_cand_cap(k) / kMsQ + 8) * 16 +
+         ((size_t)h->n_docs + (size_t)nq * ms_cand_cap(k) / kMsQ + 8) * sizeof(MsItem) +
          (size_t)nq * (32 * 512 + sizeof(float)) + 512;  // + the split image of the queries and their scales
 }
 
@@ -1389,29 +1395,29 @@ int ms_run(amdr_maxsim* h, const float* Q_dev, int nq, int q_len, int k, float* 
     int* dfill = dcnt + h->n_docs;
     int* doff = dfill + h->n_docs;            // [n_docs + 1] first pair of a document
     int* ioff = doff + h->n_docs + 1;         // [n_docs + 1] first 8-query item of a document
-    MsItem* items = reinterpret_cast<MsItem*>(((uintptr_t)(ioff + h->n_docs + 1) + 15) & ~(uintptr_t)15);
+    MsItem* items = reinterpret_cast<MsItem*>(((uintptr_t)(ioff + h->n_docs + 1) + 31) & ~(uintptr_t)31);
     unsigned char* img_q = reinterpret_cast<unsigned char*>(
         ((uintptr_t)(items + h->n_docs + (size_t)nq * cap / kMsQ + 8) + 255) & ~(uintptr_t)255);
     float* unscale_q = reinterpret_cast<float*>(img_q + (size_t)nq * 32 * 512);
     const char* rs = getenv("AMDR_MAXSIM_RESCORE");  // "0": one wave per pair (the round-3 form; A/B, tests)
     const bool by_doc = !(rs && rs[0] == '0');
     if (by_doc) AMDR_HIP(hipMemsetAsync(dcnt, 0, 2 * (size_t)h->n_docs * sizeof(int), st));
-    hipLaunchKernelGGL(maxsim_select_kernel, dim3(nq), dim3(64), (size_t)cap_sel * sizeof(C32), st, approx,
+    hipLaunchKernelGGL(maxsim_select_kernel, dim3(nq), dim3(by_doc ? 128 : 64), (size_t)cap_sel * sizeof(C32), st, approx,
                        (long)h->n_docs, Q_dev, q_len, k, cap_sel, h->d_norm_max, unscale_d, cap, exact, cand, cnt, ovf,
-                       by_doc ? dcnt : (int*)nullptr);
+                       by_doc ? dcnt : (int*)nullptr, img_q, unscale_q);
     constexpr int kPairLds = kMsWaves * 16384;
     AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_overflow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds));
     int dev = 0, cus = 256;
     AMDR_HIP(hipGetDevice(&dev));
     AMDR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     if (by_doc) {
-      hipLaunchKernelGGL(maxsim_doc_offsets_kernel, dim3(1), dim3(256), 0, st, dcnt, (long)h->n_docs, doff, ioff, items);
+      hipLaunchKernelGGL(maxsim_doc_offsets_kernel, dim3(1), dim3(256), 0, st, dcnt, (long)h->n_docs, h->doc_ptr, doff, ioff,
+                         items);
       hipLaunchKernelGGL(maxsim_pairs_fill_kernel, dim3(ceil_div((long)nq * cap, 256)), dim3(256), 0, st, cand, cnt, nq, cap,
                          doff, dfill, pairs);
       AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_rescore_ring_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    4 * 16384));
-      hipLaunchKernelGGL(ms_split_queries_kernel, dim3(nq), dim3(256), 0, st, Q_dev, q_len, img_q, unscale_q);
-      hipLaunchKernelGGL((maxsim_rescore_ring_kernel<4>), dim3(2 * cus), dim3(kMsQ * 64), 4 * 16384, st, h->img, h->doc_ptr,
+      hipLaunchKernelGGL((maxsim_rescore_ring_kernel<4>), dim3(2 * cus), dim3(kMsQ * 64), 4 * 16384, st, h->img,
                          (long)h->n_docs, img_q, unscale_q, q_len, unscale_d, items, ioff, pairs, exact);
     } else {
       AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_rescore_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds));

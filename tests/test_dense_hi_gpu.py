@@ -374,3 +374,29 @@ def test_hi_first_pass_against_the_cpu_oracle_directly(nat, monkeypatch):
                 assert np.max(np.abs(s - es)) <= 1e-4 * xs * qs * 4
             else:
                 check_dense(nat, X, Q, k)
+
+
+def test_hi_first_pass_multi_tile_passes_keep_their_thresholds(nat, monkeypatch):
+    """A pass of the round-4 tail holds up to four query tiles: ONE sample launch (a block row per tile), one threshold
+    per query, ONE scan launch that walks the tiles (AMDR_DENSE_HI_SCANS=split: a launch per tile).  With per-query lists
+    too short to hold every tile (test hook AMDR_DENSE_HI_CAP: 1 500 entries per query on 6 250 tiles) a threshold that is
+    missing or wrong for a later tile floods its lists and sends those queries through the exact chain — results stay
+    right, so only the counters show it: nothing may be unresolved, for 1 - 4 tiles and a ragged last tile."""
+    rng = np.random.default_rng(3)
+    X, Q = unit_rows(rng, 200_000, 256), unit_rows(rng, 256, 256)
+    monkeypatch.setenv("AMDR_DENSE_TWO_LEVEL", "1")
+    monkeypatch.setenv("AMDR_DENSE_HI", "0")
+    idx = nat.DenseIndex(X)
+    ref = idx.search(Q, 10)
+    idx.close()
+    monkeypatch.setenv("AMDR_DENSE_HI", "1")
+    monkeypatch.setenv("AMDR_DENSE_HI_CAP", str(64 * 1500))
+    for scans in ("one", "split"):
+        monkeypatch.setenv("AMDR_DENSE_HI_SCANS", scans)
+        for m in (64, 100, 128, 192, 256):
+            idx = nat.DenseIndex(X)
+            s, i = idx.search(Q[:m], 10)
+            took, bad, _, in_use, passes, flagged = idx.hi_counters()
+            idx.close()
+            assert (took, bad, flagged, in_use) == (m, 0, 0, True) and passes == (m + 63) // 64, (scans, m, took, bad, passes, flagged)
+            assert np.array_equal(i, ref[1][:m]) and np.array_equal(s.view(np.uint32), ref[0][:m].view(np.uint32)), (scans, m)
