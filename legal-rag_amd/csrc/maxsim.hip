@@ -738,6 +738,12 @@ __global__ __launch_bounds__(kMsQ * 64) __attribute__((amdgpu_waves_per_eu(4, 4)
 // by as many queries as before), 3 stages = 48 KiB, three blocks per CU.
 constexpr int kMsQ2 = 4;  // waves per block; 2 queries each
 
+__device__ __forceinline__ float ms_max3(float a, float b, float c) {  // max(a, b, c) in one instruction (no NaNs reach it)
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 template <int NBUF>
 __global__ __launch_bounds__(kMsQ2 * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void maxsim_hi2_ring_kernel(
     const unsigned char* __restrict__ img_hi, const long long* __restrict__ doc_ptr, long n_docs, int docs_per_block,
@@ -849,10 +855,12 @@ __global__ __launch_bounds__(kMsQ2 * 64) __attribute__((amdgpu_waves_per_eu(3, 3
         for (int j = 0; j < 16; ++j)
           if (32 * blk + (j & 3) + 8 * (j >> 2) + 4 * h >= remain) ca[j] = cb[j] = -FLT_MAX;
       }
+      // 16 values -> 1 per query and row block as EIGHT v_max3_f32 (hipcc fused only a quarter of the fmaxf pairs: 56
+      // v_max per 32 MFMAs; the pass issues ~5 other vector instructions per MFMA and its matrix pipe is busy half the time)
 #pragma unroll
       for (int j = 0; j < 16; j += 2) {
-        best_a = fmaxf(best_a, fmaxf(ca[j], ca[j + 1]));
-        best_b = fmaxf(best_b, fmaxf(cb[j], cb[j + 1]));
+        best_a = ms_max3(best_a, ca[j], ca[j + 1]);
+        best_b = ms_max3(best_b, cb[j], cb[j + 1]);
       }
     }
     if (remain <= 64) {
@@ -1112,6 +1120,9 @@ __global__ __launch_bounds__(256) void maxsim_doc_offsets_kernel(const int* __re
                                                                  int* __restrict__ doff, int* __restrict__ ioff,
                                                                  MsItem* __restrict__ items) {
   __shared__ int part[2][256];
+  __shared__ int bucket[16], bpos[16];
+  if (threadIdx.x < 16) bucket[threadIdx.x] = 0;
+  __syncthreads();
   int carry_p = 0, carry_i = 0;
   for (long base = 0; base < n_docs; base += 256) {
     const long i = base + threadIdx.x;
@@ -1129,15 +1140,12 @@ __global__ __launch_bounds__(256) void maxsim_doc_offsets_kernel(const int* __re
       __syncthreads();
     }
     if (i < n_docs) {
-      const int p0 = carry_p + part[0][threadIdx.x] - v, i0 = carry_i + part[1][threadIdx.x] - it;
-      doff[i] = p0;
-      ioff[i] = i0;
-      // the item table: the re-scoring blocks read ONE 16-byte descriptor per item instead of searching the offsets (ten
-      // dependent loads per item and wave)
-      const long long t_lo = it ? doc_ptr[i] : 0;
-      const int len = it ? (int)(doc_ptr[i + 1] - t_lo) : 0;
-      for (int c = 0; c < it; ++c)
-        items[i0 + c] = MsItem{(int)i, p0 + c * kMsQ, v - c * kMsQ < kMsQ ? v - c * kMsQ : kMsQ, len, t_lo, 0};
+      doff[i] = carry_p + part[0][threadIdx.x] - v;
+      ioff[i] = carry_i + part[1][threadIdx.x] - it;
+      if (it) {  // items per cost class: a document's items cost its tiles (longest first below)
+        const int tiles = (int)((doc_ptr[i + 1] - doc_ptr[i] + 31) >> 5);
+        atomicAdd(&bucket[15 - (tiles < 15 ? tiles : 15)], it);
+      }
     }
     carry_p += part[0][255];
     carry_i += part[1][255];
@@ -1146,6 +1154,28 @@ __global__ __launch_bounds__(256) void maxsim_doc_offsets_kernel(const int* __re
   if (threadIdx.x == 0) {
     doff[n_docs] = carry_p;
     ioff[n_docs] = carry_i;
+    int at = 0;
+    for (int c = 0; c < 16; ++c) {
+      bpos[c] = at;
+      at += bucket[c];
+    }
+  }
+  __syncthreads();
+  // The item table, LONGEST DOCUMENTS FIRST (a counting sort over the tile count): the re-scoring blocks take items
+  // b, b + grid, b + 2 grid, ... — dealt from a descending order every block's share costs about the same.  In document
+  // order a block's 4-5 items ranged from 1 to 7 tiles each and the waves were alive for 65 % of the launch (SQ_WAVE_CYCLES).
+  // One 32-byte descriptor per item: a block reads it instead of searching the offsets.
+  for (long i = threadIdx.x; i < n_docs; i += 256) {
+    const int v = dcnt[i];
+    const int it = (v + kMsQ - 1) / kMsQ;
+    if (!it) continue;
+    const long long t_lo = doc_ptr[i];
+    const int len = (int)(doc_ptr[i + 1] - t_lo);
+    const int tiles = (len + 31) >> 5;
+    const int at = atomicAdd(&bpos[15 - (tiles < 15 ? tiles : 15)], it);
+    const int p0 = doff[i];
+    for (int c = 0; c < it; ++c)
+      items[at + c] = MsItem{(int)i, p0 + c * kMsQ, v - c * kMsQ < kMsQ ? v - c * kMsQ : kMsQ, len, t_lo, 0};
   }
 }
 
