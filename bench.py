@@ -52,14 +52,18 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA == fp32 vector peak
 
 
-def kernel_sources_fingerprint():
-    """sha256 (16 hex digits) over the kernel sources: what scripts/pmc_traffic.py stamps on every traffic entry."""
+def kernel_sources_fingerprint(key):
+    """sha256 (16 hex digits) over the kernel sources the object depends on: what scripts/pmc_traffic.py stamps on its
+    traffic entry (same file lists: scripts/pmc_traffic.py SOURCES / SCAN_SOURCES)."""
     import hashlib
+    lists = {"ucc_hybrid": ("dense.hip", "dense_panel.hip", "common.hpp"),
+             "dense_only_d384": ("dense.hip", "dense_panel.hip", "common.hpp"),
+             "ucc_colbert": ("maxsim.hip", "topk.hpp", "common.hpp"),
+             "full_hybrid_rerank": ("maxsim.hip", "topk.hpp", "common.hpp")}
     h = hashlib.sha256()
-    for p in sorted((ROOT / "legal-rag_amd" / "csrc").glob("*")):
-        if p.suffix in (".hip", ".hpp", ".cpp"):
-            h.update(p.name.encode())
-            h.update(p.read_bytes())
+    for name in lists.get(key, ("dense.hip", "dense_hi.hip", "dense_mfma.hip", "topk.hpp", "common.hpp")):
+        h.update(name.encode())
+        h.update((ROOT / "legal-rag_amd" / "csrc" / name).read_bytes())
     return h.hexdigest()[:16]
 
 
@@ -72,7 +76,7 @@ def pmc_traffic(key, kernel_prefix, plan=None):
         rec = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text()).get(key)
         if not rec or not str(rec.get("kernel", "")).startswith(kernel_prefix.split("<")[0].split(" ")[0]):
             return None
-        if rec.get("sources") != kernel_sources_fingerprint():
+        if rec.get("sources") != kernel_sources_fingerprint(key):
             return None
         if plan is not None and rec.get("plan") is not None and rec["plan"] != plan:
             return None

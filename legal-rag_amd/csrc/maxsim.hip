@@ -856,7 +856,9 @@ __global__ __launch_bounds__(kMsQ2 * 64) __attribute__((amdgpu_waves_per_eu(3, 3
           if (32 * blk + (j & 3) + 8 * (j >> 2) + 4 * h >= remain) ca[j] = cb[j] = -FLT_MAX;
       }
       // 16 values -> 1 per query and row block as EIGHT v_max3_f32 (hipcc fused only a quarter of the fmaxf pairs: 56
-      // v_max per 32 MFMAs; the pass issues ~5 other vector instructions per MFMA and its matrix pipe is busy half the time)
+      // v_max per 32 MFMAs; the pass issued ~5 other vector instructions per MFMA with its matrix pipe busy half the
+      // time: 975 -> 891 us per 1 168 UCC-en queries).  Tried after it and dropped: FOUR queries per wave (64 MFMAs per
+      // tile read and barrier, 16 queries per tile, two waves per SIMD): 1.08 against 1.09 ms per hybrid step.
 #pragma unroll
       for (int j = 0; j < 16; j += 2) {
         best_a = ms_max3(best_a, ca[j], ca[j + 1]);

@@ -26,12 +26,21 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
 
-def sources_fingerprint() -> str:
+# kernel sources an object's traffic depends on: its entry is reported only while THESE files are unchanged
+SOURCES = {
+    "ucc_hybrid": ("dense.hip", "dense_panel.hip", "common.hpp"),
+    "dense_only_d384": ("dense.hip", "dense_panel.hip", "common.hpp"),
+    "ucc_colbert": ("maxsim.hip", "topk.hpp", "common.hpp"),
+    "full_hybrid_rerank": ("maxsim.hip", "topk.hpp", "common.hpp"),
+}
+SCAN_SOURCES = ("dense.hip", "dense_hi.hip", "dense_mfma.hip", "topk.hpp", "common.hpp")
+
+
+def sources_fingerprint(key: str) -> str:
     h = hashlib.sha256()
-    for p in sorted((ROOT / "legal-rag_amd" / "csrc").glob("*")):
-        if p.suffix in (".hip", ".hpp", ".cpp"):
-            h.update(p.name.encode())
-            h.update(p.read_bytes())
+    for name in SOURCES.get(key, SCAN_SOURCES):
+        h.update(name.encode())
+        h.update((ROOT / "legal-rag_amd" / "csrc" / name).read_bytes())
     return h.hexdigest()[:16]
 
 
@@ -102,7 +111,6 @@ def main():
     rec["_comment"] = ("HBM / fabric bytes per launch from rocprofv3 PMC passes (scripts/pmc_traffic.py: one --pmc pass per "
                        "counter per object; FETCH_SIZE x 2 per the gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE); "
                        "bench.py reports an entry only when its kernel, plan and `sources` fingerprint are those of the run")
-    fp = sources_fingerprint()
     report = []
     for key in want:
         cmd, kernels, plan_path = OBJECTS[key]
@@ -134,7 +142,7 @@ def main():
         if not ok:
             report.append((key, "FAILED"))
             continue
-        entry = {"round": a.round, "sources": fp, "plan": plan, "kernels": {}}
+        entry = {"round": a.round, "sources": sources_fingerprint(key), "plan": plan, "kernels": {}}
         total = 0.0
         for kname, cs in per.items():
             if "FETCH_SIZE" not in cs:

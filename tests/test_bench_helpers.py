@@ -30,13 +30,30 @@ def test_scan_algorithmic_bytes_per_plan():
     assert kern == "dense_panel_scores_kernel" and b == 591 * d * 4 + 37376 * d * 4 + 591.0 * 37376 * 4
 
 
-def test_pmc_traffic_is_keyed_on_the_kernel_that_ran():
-    rec = json.loads((Path(bench.__file__).parent / "profiles" / "pmc_traffic.json").read_text())
-    e = rec["synth10m_b64"]
-    assert bench.pmc_traffic("synth10m_b64", e["kernel"]) == float(e["bytes_per_launch"])
+def test_pmc_traffic_is_keyed_on_kernel_plan_and_sources(tmp_path, monkeypatch):
+    """bench.pmc_traffic hands out an entry of profiles/pmc_traffic.json only when it was measured (scripts/pmc_traffic.py)
+    on the kernel that ran, under the same plan string and on the same kernel SOURCES (fingerprint of the files the
+    object's kernels live in): an entry of an earlier round, another kernel or another work cut reads as None."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pmc_traffic", Path(bench.__file__).parent / "scripts" / "pmc_traffic.py")
+    pm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pm)
+    for key in ("ucc_hybrid", "dense_only_d384", "ucc_colbert", "full_hybrid_rerank", "synth10m_b64", "shard8_proxy_b64"):
+        assert pm.sources_fingerprint(key) == bench.kernel_sources_fingerprint(key), key
+    # a scratch profiles/ with one fresh and one stale entry
+    root = tmp_path / "repo"
+    (root / "profiles").mkdir(parents=True)
+    fresh = {"kernel": "dense_hi_tilemax_kernel", "plan": "P1", "sources": bench.kernel_sources_fingerprint("synth10m_b64"),
+             "bytes_per_launch": 123.0}
+    stale = dict(fresh, sources="0" * 16)
+    (root / "profiles" / "pmc_traffic.json").write_text(json.dumps({"synth10m_b64": fresh, "synth10m_b32": stale,
+                                                                    "old_style": {"kernel": "k", "bytes_per_launch": 1}}))
+    monkeypatch.setattr(bench, "ROOT", root)
+    monkeypatch.setattr(bench, "kernel_sources_fingerprint", lambda key: fresh["sources"])
+    assert bench.pmc_traffic("synth10m_b64", "dense_hi_tilemax_kernel") == 123.0
+    assert bench.pmc_traffic("synth10m_b64", "dense_hi_tilemax_kernel<12, true>", "P1") == 123.0
+    assert bench.pmc_traffic("synth10m_b64", "dense_hi_tilemax_kernel", "another plan") is None
     assert bench.pmc_traffic("synth10m_b64", "some_other_kernel") is None
-    assert bench.pmc_traffic("no_such_entry", e["kernel"]) is None
-    # traffic on record never exceeds the algorithmic bytes by more than 1 % for the HBM-bound scans
-    for key, B in (("synth10m_b4", 4), ("synth10m_b64", 64)):
-        algo = 10_000_000 * 768 * 4 + B * 768 * 4
-        assert algo <= rec[key]["bytes_per_launch"] <= 1.01 * algo + 1e8, key
+    assert bench.pmc_traffic("synth10m_b32", "dense_hi_tilemax_kernel") is None      # measured on other sources
+    assert bench.pmc_traffic("old_style", "k") is None                                # no fingerprint at all
+    assert bench.pmc_traffic("no_such_entry", "k") is None
