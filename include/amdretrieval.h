@@ -251,6 +251,19 @@ int amdr_dense_search_fuse_device(amdr_dense_t* h, const float* Q_dev, int32_t n
                                   int64_t* out_ids, double* out_vals, int32_t* out_mask, int32_t* out_count,
                                   void* stream);
 
+/* The serving call — HybridRetriever.search(), one query at a time (hybrid_retriever.py:282-384: search_dense :181-189,
+ * search_bm25 :191-209, _fuse :389-551) — as ONE launch: amdr_bm25_search_device + amdr_dense_search_fuse_device, the same
+ * five outputs bit for bit (bm25_scores/ids [nq,kb], dense_scores/ids [nq,kd], out_* as amdr_fuse_device), for 1-4
+ * queries on a corpus of <= 2 048 chunks held by both indexes on the same device with kd + kb <= 32: blocks of the one
+ * grid score the BM25 slab or 4-16 chunk rows each, and the last block of a query to arrive ranks and fuses.  Every other
+ * shape (and AMDR_HYBRID_SMALL=0) runs the two calls inside.  Only enqueues; after amdr_dense_reserve + amdr_bm25_reserve
+ * it allocates nothing (capturable).  One call at a time per pair of handles (they share the handles' workspaces). */
+int amdr_hybrid_small_device(amdr_dense_t* dense, amdr_bm25_t* bm25, const float* Q_dev, const int32_t* q_terms_dev,
+                             const int64_t* q_ptr_dev, int32_t nq, int32_t kd, int32_t kb, const amdr_fuse_params_t* p,
+                             const int64_t* dense_row2uid, const int64_t* bm25_row2uid, float* dense_scores_dev,
+                             int64_t* dense_ids_dev, double* bm25_scores_dev, int64_t* bm25_ids_dev, int64_t* out_ids,
+                             double* out_vals, int32_t* out_mask, int32_t* out_count, void* stream);
+
 /* Rerank blend over the first min(top_n, count[q]) fused hits of each query:
  * norm = minmax(ce_raw); score = (1-beta)*score + beta*norm; the candidates
  * are re-ordered by norm (stable), written back in front of the rest, and the

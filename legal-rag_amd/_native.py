@@ -29,7 +29,7 @@ FV = dict(score=0, rrf_norm=1, weighted_sum=2, dense_norm=3, bm25_norm=4, colber
 EXPORTS = (
     "amdr_last_error", "amdr_version", "amdr_device_count", "amdr_device_name",
     "amdr_dense_create", "amdr_dense_create_from_device", "amdr_dense_add", "amdr_dense_ntotal", "amdr_dense_dim",
-    "amdr_dense_reserve", "amdr_dense_search", "amdr_dense_search_device", "amdr_dense_search_fuse_device", "amdr_dense_read_rows", "amdr_dense_score_rows",
+    "amdr_dense_reserve", "amdr_dense_search", "amdr_dense_search_device", "amdr_dense_search_fuse_device", "amdr_hybrid_small_device", "amdr_dense_read_rows", "amdr_dense_score_rows",
     "amdr_dense_plan_info", "amdr_dense_workspace_plan", "amdr_dense_hi_counters", "amdr_dense_profile_begin", "amdr_dense_profile_end", "amdr_dense_destroy",
     "amdr_bm25_create", "amdr_bm25_ndocs", "amdr_bm25_reserve", "amdr_bm25_search", "amdr_bm25_search_device",
     "amdr_bm25_scores", "amdr_bm25_destroy",
@@ -50,7 +50,7 @@ SIGNATURES = {
     "amdr_last_error": "", "amdr_version": "", "amdr_device_count": "P", "amdr_device_name": "iPi",
     "amdr_dense_create": "PliiP", "amdr_dense_create_from_device": "PliiP", "amdr_dense_add": "PPl",
     "amdr_dense_ntotal": "PP", "amdr_dense_dim": "PP", "amdr_dense_reserve": "Pii", "amdr_dense_search": "PPiiPP",
-    "amdr_dense_search_device": "PPiiPPP", "amdr_dense_search_fuse_device": "PPiiPPPPiPPPPPPPP", "amdr_dense_read_rows": "PllP", "amdr_dense_score_rows": "PPiPiP",
+    "amdr_dense_search_device": "PPiiPPP", "amdr_dense_search_fuse_device": "PPiiPPPPiPPPPPPPP", "amdr_hybrid_small_device": "PPPPPiiiPPPPPPPPPPPP", "amdr_dense_read_rows": "PllP", "amdr_dense_score_rows": "PPiPiP",
     "amdr_dense_plan_info": "PiiPi", "amdr_dense_workspace_plan": "liiiP", "amdr_dense_hi_counters": "PP", "amdr_dense_profile_begin": "Pi", "amdr_dense_profile_end": "PPP", "amdr_dense_destroy": "P",
     "amdr_bm25_create": "PPPPPlldddiP", "amdr_bm25_ndocs": "PP", "amdr_bm25_reserve": "Piil",
     "amdr_bm25_search": "PPPiiPP", "amdr_bm25_search_device": "PPPiiPPP", "amdr_bm25_scores": "PPPiP",
@@ -602,6 +602,25 @@ def rerank_blend_device(nq: int, max_out: int, count: int, ids: int, vals: int, 
                                            _vp(mask), _vp(ce_raw), C.c_int32(top_n), C.c_double(beta),
                                            _vp(out_rerank), C.c_int32(device), _vp(stream)),
            "amdr_rerank_blend_device")
+
+
+def hybrid_small_plan(dense: "DenseIndex", bm25: "BM25Index", nq: int, kd: int, kb: int, dense_row2uid: int,
+                      bm25_row2uid: int, dense_scores: int, dense_ids: int, bm25_scores: int, bm25_ids: int, out_ids: int,
+                      out_vals: int, out_mask: int, out_count: int):
+    """The per-shape part of an amdr_hybrid_small_device call as ready ctypes values (the serving call is issued once per
+    query: building twenty ctypes objects per call costs more than the enqueue)."""
+    return (load().amdr_hybrid_small_device, dense._h, bm25._h, C.c_int32(nq), C.c_int32(kd), C.c_int32(kb),
+            _vp(dense_row2uid), _vp(bm25_row2uid), _vp(dense_scores), _vp(dense_ids), _vp(bm25_scores), _vp(bm25_ids),
+            _vp(out_ids), _vp(out_vals), _vp(out_mask), _vp(out_count))
+
+
+def hybrid_small_device(plan, params: "FuseParams", q_emb: int, q_terms: int, q_ptr: int, stream: int = 0) -> None:
+    """BM25 top-k + dense top-k + fusion of 1-4 queries on a serving corpus as ONE launch (amdr_hybrid_small_device);
+    every other shape runs bm25.search_device + dense.search_fuse_device inside.  Same five outputs, bit for bit."""
+    fn, dh, bh, nq, kd, kb, m0, m1, ds, di, bs, bi, oi, ov, om, oc = plan
+    rc = fn(dh, bh, q_emb, q_terms, q_ptr, nq, kd, kb, C.byref(params), m0, m1, ds, di, bs, bi, oi, ov, om, oc, stream)
+    if rc:
+        _check(rc, "amdr_hybrid_small_device")
 
 
 def fuse_compact_device(nq: int, max_out: int, w: int, ids: int, vals: int, mask: int, count: int, out_rows: int,

@@ -161,6 +161,32 @@ int dense_select_fuse_launch(const FuseTail& t, int q0, const float* S, long ldS
 int dense_fuse_plain_launch(const FuseTail& t, int q0, int m, int kd, const float* dense_scores, const int64_t* dense_ids,
                             hipStream_t st);
 
+// ---- the one-launch serving step (fuse.hip hybrid_small_kernel): what it needs from the two handles --------------
+struct DenseRaw {
+  const float* X;
+  long n;
+  int d;
+  float* S;   // [nq][ld] score scratch of the "_device" workspace
+  long ld;
+};
+// ensures the score scratch for nq rows (dense.hip)
+int dense_small_raw(amdr_dense_t* h, int nq, DenseRaw* out);
+struct Bm25Raw {
+  const long long* term_ptr;
+  const int* post_doc;
+  const double* post_w;
+  const double* idf;
+  long n_terms, n_docs;
+  int* ticket;   // [64] zeroed arrival counters of the one-launch step (self-resetting)
+  int slab, nslabs, cap, nvt;
+  size_t lds;
+  bool argmax, select_on;
+};
+int bm25_small_raw(amdr_bm25_t* h, int nq, int k, Bm25Raw* out);  // (bm25.hip)
+std::mutex& dense_mutex(amdr_dense_t* h);
+std::mutex& bm25_mutex(amdr_bm25_t* h);
+int dense_device_of(const amdr_dense_t* h);
+
 // ---- long-batch dense path: dense_panel.hip (panel of chunk rows shared by a block through LDS) ----
 struct DensePanelPlan {
   int parts, base, rem, nb, m_tiles, gm, waves;

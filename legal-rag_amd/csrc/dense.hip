@@ -10,6 +10,7 @@
 // merges the per-block lists.  HBM-bound by construction: algorithmic bytes
 // = n*d*4 per pass, flops = 2*n*d*NQ.
 #include "common.hpp"
+#include "dense_dot.hpp"
 #include "topk.hpp"
 
 #include <cfloat>
@@ -18,30 +19,6 @@
 #include <vector>
 
 namespace amdr {
-
-// --- wave64 sum via DPP: result valid in lane 63 -----------------------------
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v) {
-  int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
-  return v + __int_as_float(t);
-}
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-  v = dpp_add<0x111, 0xf>(v);  // row_shr:1
-  v = dpp_add<0x112, 0xf>(v);  // row_shr:2
-  v = dpp_add<0x114, 0xf>(v);  // row_shr:4
-  v = dpp_add<0x118, 0xf>(v);  // row_shr:8  -> lane 15 of each row = row sum
-  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1,3
-  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2,3 -> lane 63 = total
-  return v;
-}
-
-__device__ __forceinline__ float dot4(const float4& a, const float4& b, float acc) {
-  acc = fmaf(a.x, b.x, acc);
-  acc = fmaf(a.y, b.y, acc);
-  acc = fmaf(a.z, b.z, acc);
-  acc = fmaf(a.w, b.w, acc);
-  return acc;
-}
 
 constexpr int kWaves = 4;  // 256-thread blocks
 
@@ -158,15 +135,7 @@ __global__ __launch_bounds__(256) void dense_score_rows_kernel(const float* __re
     if (lane == 0) out[idx] = -FLT_MAX;
     return;
   }
-  const float* xr = X + (size_t)r * d;
-  const float* qr = Q + (size_t)qi * d;
-  float acc = 0.f;
-  for (int col = lane * 4; col < d; col += 256) {
-    const float4 a = *reinterpret_cast<const float4*>(xr + col);
-    const float4 b = *reinterpret_cast<const float4*>(qr + col);
-    acc = dot4(a, b, acc);
-  }
-  acc = wave_sum_to_lane63(acc);
+  const float acc = dense_row_dot(X + (size_t)r * d, Q + (size_t)qi * d, d, lane);
   if (lane == 63) out[idx] = acc;
 }
 
@@ -182,15 +151,7 @@ __global__ __launch_bounds__(256) void dense_all_scores_kernel(const float* __re
   if (idx >= (long)nq * n) return;
   const int qi = (int)(idx / n);
   const long r = idx - (long)qi * n;
-  const float* xr = X + (size_t)r * d;
-  const float* qr = Q + (size_t)qi * d;
-  float acc = 0.f;
-  for (int col = lane * 4; col < d; col += 256) {
-    const float4 a = *reinterpret_cast<const float4*>(xr + col);
-    const float4 b = *reinterpret_cast<const float4*>(qr + col);
-    acc = dot4(a, b, acc);
-  }
-  acc = wave_sum_to_lane63(acc);
+  const float acc = dense_row_dot(X + (size_t)r * d, Q + (size_t)qi * d, d, lane);
   if (lane == 63) S[(size_t)qi * ldS + r] = acc;
 }
 
@@ -1019,6 +980,22 @@ int update_stats(amdr_dense* h, int64_t row0, int64_t rows) {
 }
 
 }  // namespace
+
+namespace amdr {
+int dense_small_raw(amdr_dense_t* h, int nq, DenseRaw* out) {
+  const long ld = ((long)h->n + 31) / 32 * 32;
+  int rc = h->smat[0].ensure((size_t)nq * (size_t)ld * sizeof(float));
+  if (rc) return rc;
+  out->X = h->X;
+  out->n = (long)h->n;
+  out->d = h->d;
+  out->S = h->smat[0].as<float>();
+  out->ld = ld;
+  return AMDR_OK;
+}
+std::mutex& dense_mutex(amdr_dense_t* h) { return h->mu; }
+int dense_device_of(const amdr_dense_t* h) { return h->device; }
+}  // namespace amdr
 
 extern "C" {
 

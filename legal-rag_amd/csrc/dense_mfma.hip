@@ -342,18 +342,6 @@ __global__ __launch_bounds__(WAVES * 64) void dense_mfma_scores_kernel(const flo
   }
 }
 
-constexpr int kSelectRowsMax = 2048;  // rows one wave ranks in registers (<= 32 keys per lane)
-
-template <int V>
-__device__ __forceinline__ int select_row(const float* __restrict__ row, long lo, long hi, int k, int lane, C32* buf) {
-  C32 keys[V];
-#pragma unroll
-  for (int v = 0; v < V; ++v) {
-    const long r = lo + lane + 64 * v;
-    keys[v] = (r < hi) ? C32::make(row[r], (u32)r) : C32::pad();
-  }
-  return wave_select_small<C32, V>(keys, k, buf + 64, lane, buf);
-}
 
 // grid: (x = row slabs, y = queries): top-k of S[q][slab] -> part[slab][q][k], or, when there
 // is a single slab, straight to the final (scores, ids).  WAVES = 1 for short rows.

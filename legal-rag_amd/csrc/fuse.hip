@@ -9,7 +9,9 @@
 // Every expression below is written in the reference's operand order and this
 // file is compiled with -ffp-contract=off so results are bit-identical to the
 // Python float arithmetic.  Exactly tied scores keep first-appearance order.
+#include "bm25_core.hpp"
 #include "common.hpp"
+#include "dense_dot.hpp"
 #include "topk.hpp"
 
 #include <cfloat>
@@ -299,14 +301,14 @@ template <int W, bool PRE>
 __device__ __forceinline__ void fuse_packed_body(const amdr_fuse_params_t& P, const ChanIn& c0, const ChanIn& c1,
                                                  const ChanIn& c2, int nq, int max_out, long long* __restrict__ out_ids,
                                                  double* __restrict__ out_vals, int* __restrict__ out_mask,
-                                                 int* __restrict__ out_count, const FusePre& pre) {
+                                                 int* __restrict__ out_count, const FusePre& pre, int qbase) {
   constexpr int G = 64 / W;  // queries per wave
   __shared__ long long s_uid[G][W];
   __shared__ double s_sc[G][W];
   __shared__ double s_chs[G][3][W];  // channel scores by list position
   __shared__ int s_pos[G][3][W];
   const int lane = threadIdx.x, seg = lane / W, sl = lane % W;
-  const int qi = blockIdx.x * G + seg;
+  const int qi = qbase + seg;  // (the packed kernels: blockIdx.x * G)
   const bool live = qi < nq;
   const ChanIn ch[3] = {c0, c1, c2};
   const double w[3] = {P.w_dense, P.w_bm25, P.w_colbert};
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(64) void fuse_packed_kernel(amdr_fuse_params_t P, C
                                                          int* __restrict__ out_count) {
   FusePre none;
   none.have[0] = none.have[1] = none.have[2] = false;
-  fuse_packed_body<W, false>(P, c0, c1, c2, nq, max_out, out_ids, out_vals, out_mask, out_count, none);
+  fuse_packed_body<W, false>(P, c0, c1, c2, nq, max_out, out_ids, out_vals, out_mask, out_count, none, blockIdx.x * (64 / W));
 }
 
 // Dense top-k + fusion in ONE kernel for the serving shape under a batch (dense + BM25, <= 1 024 rows, kd + kb <= 32):
@@ -540,7 +542,136 @@ __global__ __launch_bounds__(64) void dense_select_fuse_kernel(amdr_fuse_params_
   none.row2uid = nullptr;
   none.k = 0;
   none.is_f64 = 0;
-  fuse_packed_body<32, true>(P, c0, c1, none, nq, max_out, out_ids, out_vals, out_mask, out_count, pre);
+  fuse_packed_body<32, true>(P, c0, c1, none, nq, max_out, out_ids, out_vals, out_mask, out_count, pre, blockIdx.x * 2);
+}
+
+// ---- the serving call in ONE launch ------------------------------------------------------------------------------------
+// HybridRetriever.search() issues one query at a time (hybrid_retriever.py:282-384); on a serving corpus (591 / 1 260
+// chunks) its dense + BM25 step was FOUR short launches — BM25 scoring + top-k, one wave per (query, row) of dense scores,
+// the dense top-k, the fusion — 45 us of which ~15 are kernels.  Here one launch does all four for 1-4 queries on a
+// corpus of <= 2 048 chunks: blocks take ROLES — block 0 of a query is its BM25 wave (bm25_core.hpp bm25_block_query: the
+// channel's own code), blocks 1.. take 16 chunk rows each (dense_dot.hpp dense_row_dot: one wave per row, the GEMV
+// form's instruction sequence) — and the LAST block of a query to arrive (one ticket per block: every storing wave
+// drains its stores, the block's lane 0 releases at agent scope and takes a ticket; the last ticket holder acquires —
+// MI355X_MICROARCH.md, inter-workgroup visibility) ranks the dense scores (the register selector of the slab top-k) and
+// fuses with the BM25 list (fuse_packed_body, the packed fusion's code): the same instructions as the four launches,
+// hence the same bits (tests/test_kernels_gpu.py).  The ticket counter resets itself.
+struct SmallArgs {
+  // BM25 role
+  const long long* term_ptr;
+  const int* post_doc;
+  const double* post_w;
+  const double* idf;
+  long n_terms, n_docs;
+  const int* q_terms;
+  const long long* q_ptr;
+  int kb, cap, slab, use_select;
+  double* bm_scores;     // [nq, kb]
+  long long* bm_ids;
+  // dense role
+  const float* X;
+  const float* Q;
+  long n_rows;
+  int d, rows_per_block, blocks_per_query;
+  float* S;              // [nq, ldS]
+  long ldS;
+  int kd, cap_sel;
+  float* d_scores;       // [nq, kd]
+  long long* d_ids;
+  int* ticket;           // [>= nq] zero before the launch, zero after
+};
+
+template <int NVT>
+__global__ __launch_bounds__(256) void hybrid_small_kernel(SmallArgs A, amdr_fuse_params_t P, ChanIn c0, ChanIn c1, int nq,
+                                                           int max_out, long long* __restrict__ out_ids,
+                                                           double* __restrict__ out_vals, int* __restrict__ out_mask,
+                                                           int* __restrict__ out_count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int s_last;
+  const int q = blockIdx.y, role = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (role == 0) {
+    if (wave == 0)
+      bm25_block_query<1, NVT>(A.term_ptr, A.post_doc, A.post_w, A.idf, A.n_terms, A.n_docs, A.q_terms, A.q_ptr, nq, A.kb,
+                               A.cap, A.slab, A.use_select, nullptr, nullptr, A.bm_scores, A.bm_ids, q, 0, smem);
+  } else {
+    const long r0 = (long)(role - 1) * A.rows_per_block;
+    long r1 = r0 + A.rows_per_block;
+    if (r1 > A.n_rows) r1 = A.n_rows;
+    for (long r = r0 + wave; r < r1; r += 4) {
+      const float acc = dense_row_dot(A.X + (size_t)r * A.d, A.Q + (size_t)q * A.d, A.d, lane);
+      if (lane == 63) A.S[(size_t)q * A.ldS + r] = acc;
+    }
+  }
+  // ---- arrive: the stores of every wave of the block are out, one release, one ticket
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int t = __hip_atomic_fetch_add(A.ticket + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == A.blocks_per_query - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last || wave != 0) return;  // block-uniform flag; the tail is one wave
+  if (lane == 0) __hip_atomic_store(A.ticket + q, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // ---- the last block's wave 0: dense top-k of row q (scores_slab_topk_kernel<1>'s selection), then the fusion
+  C32* buf = reinterpret_cast<C32*>(smem);
+  const float* row = A.S + (size_t)q * A.ldS;
+  const long n = A.n_rows;
+  WaveTopK<C32> tk;
+  tk.init(buf, A.cap_sel, A.kd);
+  int got;
+  if (n <= 256)
+    got = select_row<4>(row, 0, n, A.kd, lane, tk.buf);
+  else if (n <= 640)
+    got = select_row<10>(row, 0, n, A.kd, lane, tk.buf);
+  else if (n <= 1024)
+    got = select_row<16>(row, 0, n, A.kd, lane, tk.buf);
+  else if (n <= 1280)
+    got = select_row<20>(row, 0, n, A.kd, lane, tk.buf);
+  else
+    got = select_row<32>(row, 0, n, A.kd, lane, tk.buf);
+  if (got >= 0) {
+    tk.cnt = got;
+  } else {  // mass ties at the cut: the staged selector
+    for (long base = 0; base < n; base += 64) {
+      const long r = base + lane;
+      const bool v = r < n;
+      tk.push_lanes(v ? C32::make(row[r], (u32)r) : C32::pad(), v, lane);
+    }
+    tk.finalize(lane);
+  }
+  wave_lds_fence();
+  const int sl = lane & 31;
+  const bool v = lane < 32 && sl < tk.cnt;
+  const C32 mine = v ? tk.buf[sl] : C32::pad();
+  if (lane < A.kd) {
+    A.d_scores[(size_t)q * A.kd + lane] = v ? mine.score() : -FLT_MAX;
+    A.d_ids[(size_t)q * A.kd + lane] = v ? mine.id() : -1ll;
+  }
+  FusePre pre;
+  pre.have[0] = pre.have[1] = true;
+  pre.have[2] = false;
+  pre.id[0] = v ? mine.id() : -1ll;
+  pre.s[0] = v ? (double)mine.score() : 0.0;
+  pre.id[1] = -1;
+  pre.s[1] = 0.0;
+  if (lane < 32 && sl < c1.k) {
+    pre.id[1] = c1.ids[(size_t)q * c1.k + sl];
+    pre.s[1] = chan_score(c1, q, sl);
+  }
+  wave_lds_fence();
+  ChanIn none;
+  none.ids = nullptr;
+  none.scores = nullptr;
+  none.row2uid = nullptr;
+  none.k = 0;
+  none.is_f64 = 0;
+  // segment 0 (lanes 0-31) = query q, segment 1 has no query (q + 1 >= the limit handed in)
+  fuse_packed_body<32, true>(P, c0, c1, none, q + 1, max_out, out_ids, out_vals, out_mask, out_count, pre, q);
 }
 
 // fuse_kernel for long candidate lists, the packed forms when a query fits in 32 or 16 lanes
@@ -671,6 +802,81 @@ int dense_fuse_plain_launch(const FuseTail& t, int q0, int m, int kd, const floa
   ChanIn c2{nullptr, nullptr, nullptr, 0, 0};
   launch_fuse(*t.p, c0, c1, c2, m, mo, (long long*)(t.out_ids + (size_t)q0 * mo),
               t.out_vals + (size_t)q0 * mo * AMDR_FUSE_NVALS, t.out_mask + (size_t)q0 * mo, t.out_count + q0, st);
+  AMDR_HIP(hipGetLastError());
+  return AMDR_OK;
+}
+
+// AMDR_HYBRID_SMALL=0 pins the separate launches (A/B and tests)
+bool hybrid_small_applies(long n_dense, long n_bm25, int nslabs, int nq, int kd, int kb) {
+  const char* e = getenv("AMDR_HYBRID_SMALL");
+  if (e && e[0] == '0') return false;
+  return nq >= 1 && nq <= 4 && n_dense >= 1 && n_dense <= kSelectRowsMax && n_bm25 >= 1 && nslabs == 1 && kd >= 1 && kb >= 1 &&
+         kd + kb <= 32;
+}
+
+static int hybrid_small_rows() {  // chunk rows per dense block (4 waves): AMDR_HYBRID_SMALL_ROWS, multiple of 4
+  static const int rows = [] {
+    const char* e = getenv("AMDR_HYBRID_SMALL_ROWS");
+    int r = e ? atoi(e) : 8;
+    if (r < 4) r = 4;
+    if (r > 64) r = 64;
+    return (r + 3) / 4 * 4;
+  }();
+  return rows;
+}
+
+int hybrid_small_launch(const DenseRaw& dr, const Bm25Raw& br, const float* Q, const int* q_terms, const long long* q_ptr,
+                        int nq, int kd, int kb, const amdr_fuse_params_t& P, const int64_t* dense_row2uid,
+                        const int64_t* bm25_row2uid, float* dense_scores, int64_t* dense_ids, double* bm25_scores,
+                        int64_t* bm25_ids, int64_t* out_ids, double* out_vals, int32_t* out_mask, int32_t* out_count,
+                        hipStream_t st) {
+  SmallArgs A;
+  A.term_ptr = br.term_ptr;
+  A.post_doc = br.post_doc;
+  A.post_w = br.post_w;
+  A.idf = br.idf;
+  A.n_terms = br.n_terms;
+  A.n_docs = br.n_docs;
+  A.q_terms = q_terms;
+  A.q_ptr = q_ptr;
+  A.kb = kb;
+  A.cap = br.cap;
+  A.slab = br.slab;
+  A.use_select = br.select_on ? 1 : 0;
+  A.bm_scores = bm25_scores;
+  A.bm_ids = (long long*)bm25_ids;
+  A.X = dr.X;
+  A.Q = Q;
+  A.d = dr.d;
+  A.n_rows = dr.n;
+  A.rows_per_block = hybrid_small_rows();
+  const int dense_blocks = (int)((dr.n + A.rows_per_block - 1) / A.rows_per_block);
+  A.blocks_per_query = 1 + dense_blocks;
+  A.S = dr.S;
+  A.ldS = dr.ld;
+  A.kd = kd;
+  int cap_sel = topk_cap(kd);
+  if (cap_sel < 128) cap_sel = 128;
+  A.cap_sel = cap_sel;
+  A.d_scores = dense_scores;
+  A.d_ids = (long long*)dense_ids;
+  A.ticket = br.ticket;
+  size_t lds = br.lds;
+  if (lds < (size_t)cap_sel * sizeof(C32)) lds = (size_t)cap_sel * sizeof(C32);
+  const int mo = kd + kb;
+  ChanIn c0{nullptr, nullptr, (const long long*)dense_row2uid, kd, 0};
+  ChanIn c1{(const long long*)bm25_ids, (const void*)bm25_scores, (const long long*)bm25_row2uid, kb, 1};
+#define AMDR_HS_LAUNCH(NVT)                                                                                        \
+  hipLaunchKernelGGL((hybrid_small_kernel<NVT>), dim3(A.blocks_per_query, nq), dim3(256), lds, st, A, P, c0, c1, nq, mo, \
+                     (long long*)out_ids, out_vals, out_mask, out_count)
+  const int nv = br.nvt;  // (bm_run's choice of register bucket)
+  if (nv <= 4) AMDR_HS_LAUNCH(4);
+  else if (nv <= 8) AMDR_HS_LAUNCH(8);
+  else if (nv <= 10) AMDR_HS_LAUNCH(10);
+  else if (nv <= 16) AMDR_HS_LAUNCH(16);
+  else if (nv <= 20) AMDR_HS_LAUNCH(20);
+  else AMDR_HS_LAUNCH(32);
+#undef AMDR_HS_LAUNCH
   AMDR_HIP(hipGetLastError());
   return AMDR_OK;
 }
@@ -909,5 +1115,47 @@ int amdr_rerank_blend(int32_t nq, int32_t max_out, const int32_t* count, int64_t
   memcpy(out_rerank, hb.data() + o_o, q * mo * 16);
   return AMDR_OK;
 }
+
+int amdr_hybrid_small_device(amdr_dense_t* dense, amdr_bm25_t* bm25, const float* Q_dev, const int32_t* q_terms_dev,
+                             const int64_t* q_ptr_dev, int32_t nq, int32_t kd, int32_t kb, const amdr_fuse_params_t* p,
+                             const int64_t* dense_row2uid, const int64_t* bm25_row2uid, float* dense_scores_dev,
+                             int64_t* dense_ids_dev, double* bm25_scores_dev, int64_t* bm25_ids_dev, int64_t* out_ids,
+                             double* out_vals, int32_t* out_mask, int32_t* out_count, void* stream) {
+  AMDR_REQUIRE(dense && bm25, "hybrid_small: null index handle");
+  AMDR_REQUIRE(p != nullptr, "hybrid_small: null params");
+  AMDR_REQUIRE(p->method >= 0 && p->method <= AMDR_FUSE_WEIGHTED_SUM, "hybrid_small: method=%d", p->method);
+  AMDR_REQUIRE(nq >= 0 && kd >= 1 && kd <= AMDR_MAX_K && kb >= 1 && kb <= AMDR_MAX_K, "hybrid_small: bad sizes");
+  if (nq == 0) return AMDR_OK;
+  AMDR_REQUIRE(Q_dev && q_terms_dev && q_ptr_dev, "hybrid_small: null query buffers");
+  AMDR_REQUIRE(dense_scores_dev && dense_ids_dev && bm25_scores_dev && bm25_ids_dev, "hybrid_small: null channel lists");
+  AMDR_REQUIRE(out_ids && out_vals && out_mask && out_count, "hybrid_small: null output");
+  int64_t nd = 0, nb = 0;
+  int rc;
+  if ((rc = amdr_dense_ntotal(dense, &nd))) return rc;
+  if ((rc = amdr_bm25_ndocs(bm25, &nb))) return rc;
+  AMDR_REQUIRE(kd <= nd || nd == 0, "hybrid_small: kd=%d > %lld rows", kd, (long long)nd);
+  bool one = false;
+  if (nd >= 1 && nb >= 1 && nq <= 4 && dense_device_of(dense) >= 0) {
+    std::lock_guard<std::mutex> gd(dense_mutex(dense));
+    std::lock_guard<std::mutex> gb(bm25_mutex(bm25));
+    AMDR_HIP(hipSetDevice(dense_device_of(dense)));
+    Bm25Raw br;
+    if ((rc = bm25_small_raw(bm25, nq, kb, &br))) return rc;
+    if (hybrid_small_applies((long)nd, (long)nb, br.nslabs, nq, kd, kb)) {
+      DenseRaw dr;
+      if ((rc = dense_small_raw(dense, nq, &dr))) return rc;
+      one = true;
+      rc = hybrid_small_launch(dr, br, Q_dev, q_terms_dev, (const long long*)q_ptr_dev, nq, kd, kb, *p, dense_row2uid,
+                               bm25_row2uid, dense_scores_dev, dense_ids_dev, bm25_scores_dev, bm25_ids_dev, out_ids,
+                               out_vals, out_mask, out_count, (hipStream_t)stream);
+    }
+  }
+  if (one) return rc;
+  if ((rc = amdr_bm25_search_device(bm25, q_terms_dev, q_ptr_dev, nq, kb, bm25_scores_dev, bm25_ids_dev, stream))) return rc;
+  return amdr_dense_search_fuse_device(dense, Q_dev, nq, kd, p, dense_row2uid, bm25_ids_dev, bm25_scores_dev, kb,
+                                       bm25_row2uid, dense_scores_dev, dense_ids_dev, out_ids, out_vals, out_mask,
+                                       out_count, stream);
+}
+
 
 }  // extern "C"

@@ -489,6 +489,20 @@ __device__ inline int wave_select_small_pair32(const u32 (&sk)[V], IdOf&& id_of,
   return cnt;
 }
 
+// Top-k of a row of <= 64 V fp32 scores by ONE wave in registers (wave_select_small): keys (score, column), the sorted
+// list in buf[0 .. k), scratch buf[64 .. 128).  -1: mass ties at the cut, the caller takes the staged selector.
+constexpr int kSelectRowsMax = 2048;  // rows one wave ranks in registers (<= 32 keys per lane)
+template <int V>
+__device__ __forceinline__ int select_row(const float* __restrict__ row, long lo, long hi, int k, int lane, C32* buf) {
+  C32 keys[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const long r = lo + lane + 64 * v;
+    keys[v] = (r < hi) ? C32::make(row[r], (u32)r) : C32::pad();
+  }
+  return wave_select_small<C32, V>(keys, k, buf + 64, lane, buf);
+}
+
 typedef float tk_v4f __attribute__((ext_vector_type(4)));
 
 // Two queries per wave (lanes 0-31 / 32-63), for rows of <= 1024 scores at k <= 32 when there is a

@@ -202,6 +202,35 @@ class HybridEngine:
                                       vals.data_ptr(), mask.data_ptr(), count.data_ptr(), _stream())
         return (s, i), BatchResult(ids=ids, vals=vals, mask=mask, count=count, packed=pk)
 
+    def _hybrid_small(self, params: _native.FuseParams, q_emb: torch.Tensor, q_terms: torch.Tensor, q_ptr: torch.Tensor,
+                      k: int) -> BatchResult:
+        """bm25_topk + dense_topk_fuse through amdr_hybrid_small_device (one launch on a serving corpus).  Issued once
+        per query by search(): output tensors and the call's argument block are built once per (nq, k)."""
+        nq = int(q_emb.shape[0])
+        assert q_emb.is_cuda and q_emb.dtype == torch.float32 and q_emb.is_contiguous()
+        assert q_terms.dtype == torch.int32 and q_ptr.dtype == torch.int64 and q_terms.is_cuda and q_ptr.is_cuda
+        assert q_ptr.shape[0] - 1 == nq
+        ent = self._xcache.get(("hs", nq, k))
+        if ent is None:
+            ds = self._buf("ds", (nq, k), torch.float32)
+            di = self._buf("di", (nq, k), torch.int64)
+            bs = self._buf("bs", (nq, k), torch.float64)
+            bi = self._buf("bi", (nq, k), torch.int64)
+            pk, ids, vals, mask, count = self._fused_outputs(nq, 2 * k)
+            m0, m1 = self.maps[0], self.maps[1]
+            plan = _native.hybrid_small_plan(self.dense, self.bm25, nq, k, k, m0.data_ptr() if m0 is not None else 0,
+                                             m1.data_ptr() if m1 is not None else 0, ds.data_ptr(), di.data_ptr(),
+                                             bs.data_ptr(), bi.data_ptr(), ids.data_ptr(), vals.data_ptr(), mask.data_ptr(),
+                                             count.data_ptr())
+            ent = (plan, (ids, vals, mask, count, pk), (ds, di, bs, bi))
+            self._xcache[("hs", nq, k)] = ent
+        plan, (ids, vals, mask, count, pk), (ds, di, bs, bi) = ent
+        _native.hybrid_small_device(plan, params, q_emb.data_ptr(), q_terms.data_ptr(), q_ptr.data_ptr(), _stream())
+        res = BatchResult(ids=ids, vals=vals, mask=mask, count=count, packed=pk)
+        res.dense_scores, res.dense_ids = ds, di
+        res.bm25_scores, res.bm25_ids = bs, bi
+        return res
+
     def rerank_blend(self, res: BatchResult, ce_raw: torch.Tensor, beta: float) -> BatchResult:
         nq, mo = res.ids.shape
         assert ce_raw.is_cuda and ce_raw.dtype == torch.float64 and ce_raw.is_contiguous() and ce_raw.shape[0] == nq
@@ -223,6 +252,10 @@ class HybridEngine:
                 and not (self.maxsim is not None and q_tok is not None) and self.shard_offset is None):
             # dense + BM25 on one GPU, the serving hybrid without ColBERT: BM25 first, then the dense channel and the
             # fusion in one native call
+            nq = int(q_emb.shape[0])
+            if nq <= 4 and 2 * k <= 32:
+                # the serving call (search(): one query at a time): both channels and the fusion in ONE launch
+                return self._hybrid_small(params, q_emb, q_terms, q_ptr, k)
             b = self.bm25_topk(q_terms, q_ptr, k)
             d, res = self.dense_topk_fuse(params, q_emb, k, b)
             res.dense_scores, res.dense_ids = d
