@@ -551,11 +551,12 @@ __global__ __launch_bounds__(64) void dense_select_fuse_kernel(amdr_fuse_params_
 // the dense top-k, the fusion — 45 us of which ~15 are kernels.  Here one launch does all four for 1-4 queries on a
 // corpus of <= 2 048 chunks: blocks take ROLES — block 0 of a query is its BM25 wave (bm25_core.hpp bm25_block_query: the
 // channel's own code), blocks 1.. take 16 chunk rows each (dense_dot.hpp dense_row_dot: one wave per row, the GEMV
-// form's instruction sequence) — and the LAST block of a query to arrive (one ticket per block: every storing wave
-// drains its stores, the block's lane 0 releases at agent scope and takes a ticket; the last ticket holder acquires —
-// MI355X_MICROARCH.md, inter-workgroup visibility) ranks the dense scores (the register selector of the slab top-k) and
-// fuses with the BM25 list (fuse_packed_body, the packed fusion's code): the same instructions as the four launches,
-// hence the same bits (tests/test_kernels_gpu.py).  The ticket counter resets itself.
+// form's instruction sequence) — and hand over through two self-resetting arrival counters per query (a wave
+// drains its stores, releases at agent scope and takes a ticket; the last ticket holder acquires — MI355X_MICROARCH.md,
+// inter-workgroup visibility): the LAST dense block to arrive ranks the score row (the register selector of the slab
+// top-k) while the BM25 wave is still scoring, and the SECOND of the two finished channel lists to arrive fuses
+// (fuse_packed_body, the packed fusion's code).  The same instructions as the four launches, hence the same bits
+// (tests/test_hybrid_small_gpu.py).
 struct SmallArgs {
   // BM25 role
   const long long* term_ptr;
@@ -581,20 +582,45 @@ struct SmallArgs {
   int* ticket;           // [>= nq] zero before the launch, zero after
 };
 
+// one wave's arrival at a counter: its stores are out and released at agent scope; returns the ticket (wave-uniform)
+__device__ __forceinline__ int small_arrive(int* counter, int lane) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  int t = 0;
+  if (lane == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return __builtin_amdgcn_readfirstlane(t);
+}
+__device__ __forceinline__ void small_acquire(int* counter, int lane) {
+  if (lane == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 template <int NVT>
 __global__ __launch_bounds__(256) void hybrid_small_kernel(SmallArgs A, amdr_fuse_params_t P, ChanIn c0, ChanIn c1, int nq,
                                                            int max_out, long long* __restrict__ out_ids,
                                                            double* __restrict__ out_vals, int* __restrict__ out_mask,
                                                            int* __restrict__ out_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ int s_last;
   const int q = blockIdx.y, role = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int* rows_done = A.ticket + q;       // arrivals of the dense blocks of query q
+  int* lists_done = A.ticket + 32 + q; // arrivals of its two channel lists
+  const int sl = lane & 31;
+  FusePre pre;
+  pre.have[0] = pre.have[1] = true;
+  pre.have[2] = false;
+  bool have_dense = false;  // this wave ranked the dense row itself: the list is in its lanes
   if (role == 0) {
-    if (wave == 0)
-      bm25_block_query<1, NVT>(A.term_ptr, A.post_doc, A.post_w, A.idf, A.n_terms, A.n_docs, A.q_terms, A.q_ptr, nq, A.kb,
-                               A.cap, A.slab, A.use_select, nullptr, nullptr, A.bm_scores, A.bm_ids, q, 0, smem);
+    // ---- the BM25 channel of query q: one wave, the channel's own code; the other three have nothing to do
+    if (wave != 0) return;
+    bm25_block_query<1, NVT>(A.term_ptr, A.post_doc, A.post_w, A.idf, A.n_terms, A.n_docs, A.q_terms, A.q_ptr, nq, A.kb,
+                             A.cap, A.slab, A.use_select, nullptr, nullptr, A.bm_scores, A.bm_ids, q, 0, smem);
   } else {
+    // ---- rows_per_block chunk rows of the dense channel, one wave per row (the GEMV form's dot product)
     const long r0 = (long)(role - 1) * A.rows_per_block;
     long r1 = r0 + A.rows_per_block;
     if (r1 > A.n_rows) r1 = A.n_rows;
@@ -602,68 +628,69 @@ __global__ __launch_bounds__(256) void hybrid_small_kernel(SmallArgs A, amdr_fus
       const float acc = dense_row_dot(A.X + (size_t)r * A.d, A.Q + (size_t)q * A.d, A.d, lane);
       if (lane == 63) A.S[(size_t)q * A.ldS + r] = acc;
     }
-  }
-  // ---- arrive: the stores of every wave of the block are out, one release, one ticket
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int t = __hip_atomic_fetch_add(A.ticket + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (t == A.blocks_per_query - 1) ? 1 : 0;
-  }
-  __syncthreads();
-  if (!s_last || wave != 0) return;  // block-uniform flag; the tail is one wave
-  if (lane == 0) __hip_atomic_store(A.ticket + q, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  // ---- the last block's wave 0: dense top-k of row q (scores_slab_topk_kernel<1>'s selection), then the fusion
-  C32* buf = reinterpret_cast<C32*>(smem);
-  const float* row = A.S + (size_t)q * A.ldS;
-  const long n = A.n_rows;
-  WaveTopK<C32> tk;
-  tk.init(buf, A.cap_sel, A.kd);
-  int got;
-  if (n <= 256)
-    got = select_row<4>(row, 0, n, A.kd, lane, tk.buf);
-  else if (n <= 640)
-    got = select_row<10>(row, 0, n, A.kd, lane, tk.buf);
-  else if (n <= 1024)
-    got = select_row<16>(row, 0, n, A.kd, lane, tk.buf);
-  else if (n <= 1280)
-    got = select_row<20>(row, 0, n, A.kd, lane, tk.buf);
-  else
-    got = select_row<32>(row, 0, n, A.kd, lane, tk.buf);
-  if (got >= 0) {
-    tk.cnt = got;
-  } else {  // mass ties at the cut: the staged selector
-    for (long base = 0; base < n; base += 64) {
-      const long r = base + lane;
-      const bool v = r < n;
-      tk.push_lanes(v ? C32::make(row[r], (u32)r) : C32::pad(), v, lane);
+    __syncthreads();  // every wave's scores are out
+    if (wave != 0) return;
+    if (small_arrive(rows_done, lane) != A.blocks_per_query - 2) return;
+    // ---- the last dense block to arrive: top-k of row q (scores_slab_topk_kernel<1>'s selection)
+    small_acquire(rows_done, lane);
+    C32* buf = reinterpret_cast<C32*>(smem);
+    const float* row = A.S + (size_t)q * A.ldS;
+    const long n = A.n_rows;
+    WaveTopK<C32> tk;
+    tk.init(buf, A.cap_sel, A.kd);
+    int got;
+    if (n <= 256)
+      got = select_row<4>(row, 0, n, A.kd, lane, tk.buf);
+    else if (n <= 640)
+      got = select_row<10>(row, 0, n, A.kd, lane, tk.buf);
+    else if (n <= 1024)
+      got = select_row<16>(row, 0, n, A.kd, lane, tk.buf);
+    else if (n <= 1280)
+      got = select_row<20>(row, 0, n, A.kd, lane, tk.buf);
+    else
+      got = select_row<32>(row, 0, n, A.kd, lane, tk.buf);
+    if (got >= 0) {
+      tk.cnt = got;
+    } else {  // mass ties at the cut: the staged selector
+      for (long base = 0; base < n; base += 64) {
+        const long r = base + lane;
+        const bool v = r < n;
+        tk.push_lanes(v ? C32::make(row[r], (u32)r) : C32::pad(), v, lane);
+      }
+      tk.finalize(lane);
     }
-    tk.finalize(lane);
+    wave_lds_fence();
+    const bool v = lane < 32 && sl < tk.cnt;
+    const C32 mine = v ? tk.buf[sl] : C32::pad();
+    if (lane < A.kd) {
+      A.d_scores[(size_t)q * A.kd + lane] = v ? mine.score() : -FLT_MAX;
+      A.d_ids[(size_t)q * A.kd + lane] = v ? mine.id() : -1ll;
+    }
+    pre.id[0] = v ? mine.id() : -1ll;
+    pre.s[0] = v ? (double)mine.score() : 0.0;
+    have_dense = true;
+    wave_lds_fence();
   }
-  wave_lds_fence();
-  const int sl = lane & 31;
-  const bool v = lane < 32 && sl < tk.cnt;
-  const C32 mine = v ? tk.buf[sl] : C32::pad();
-  if (lane < A.kd) {
-    A.d_scores[(size_t)q * A.kd + lane] = v ? mine.score() : -FLT_MAX;
-    A.d_ids[(size_t)q * A.kd + lane] = v ? mine.id() : -1ll;
+  // ---- a finished channel list; the second of the two to arrive fuses (the BM25 wave while the dense rows were being
+  // ranked elsewhere, or the ranking wave when BM25 finished first)
+  if (small_arrive(lists_done, lane) != 1) return;
+  small_acquire(lists_done, lane);
+  if (!have_dense) {
+    pre.id[0] = -1;
+    pre.s[0] = 0.0;
+    if (lane < 32 && sl < A.kd) {
+      const long long id = A.d_ids[(size_t)q * A.kd + sl];
+      pre.id[0] = id;
+      pre.s[0] = id >= 0 ? (double)A.d_scores[(size_t)q * A.kd + sl] : 0.0;
+    }
   }
-  FusePre pre;
-  pre.have[0] = pre.have[1] = true;
-  pre.have[2] = false;
-  pre.id[0] = v ? mine.id() : -1ll;
-  pre.s[0] = v ? (double)mine.score() : 0.0;
   pre.id[1] = -1;
   pre.s[1] = 0.0;
   if (lane < 32 && sl < c1.k) {
     pre.id[1] = c1.ids[(size_t)q * c1.k + sl];
     pre.s[1] = chan_score(c1, q, sl);
   }
-  wave_lds_fence();
   ChanIn none;
   none.ids = nullptr;
   none.scores = nullptr;
@@ -814,15 +841,20 @@ bool hybrid_small_applies(long n_dense, long n_bm25, int nslabs, int nq, int kd,
          kd + kb <= 32;
 }
 
-static int hybrid_small_rows() {  // chunk rows per dense block (4 waves): AMDR_HYBRID_SMALL_ROWS, multiple of 4
-  static const int rows = [] {
+// chunk rows per dense block (4 waves).  Every block costs an arrival (one atomic on the query's counter) and a block
+// start; measured on 591 x 384 ... 2 048 x 768, 1-4 queries (scripts/ab_hybrid_small.py): 16 rows up to ~2 500
+// (query, row) pairs, 32 beyond.  AMDR_HYBRID_SMALL_ROWS pins a value (multiple of 4).
+static int hybrid_small_rows(long n, int nq) {
+  static const int pinned = [] {
     const char* e = getenv("AMDR_HYBRID_SMALL_ROWS");
-    int r = e ? atoi(e) : 8;
+    int r = e ? atoi(e) : 0;
+    if (r <= 0) return 0;
     if (r < 4) r = 4;
     if (r > 64) r = 64;
     return (r + 3) / 4 * 4;
   }();
-  return rows;
+  if (pinned) return pinned;
+  return n * nq <= 2560 ? 16 : 32;
 }
 
 int hybrid_small_launch(const DenseRaw& dr, const Bm25Raw& br, const float* Q, const int* q_terms, const long long* q_ptr,
@@ -849,7 +881,7 @@ int hybrid_small_launch(const DenseRaw& dr, const Bm25Raw& br, const float* Q, c
   A.Q = Q;
   A.d = dr.d;
   A.n_rows = dr.n;
-  A.rows_per_block = hybrid_small_rows();
+  A.rows_per_block = hybrid_small_rows(dr.n, nq);
   const int dense_blocks = (int)((dr.n + A.rows_per_block - 1) / A.rows_per_block);
   A.blocks_per_query = 1 + dense_blocks;
   A.S = dr.S;

@@ -123,12 +123,31 @@ class HashingTokenEmbedder:
 class HashingCrossScorer:
     """Stand-in for the cross-encoder: sigmoid of a token-overlap statistic."""
 
+    _DOC_CACHE_MAX = 1 << 16
+
+    def __init__(self):
+        self._docs = {}  # text -> (token counts, token total): a corpus chunk is scored against many queries
+
+    def _doc(self, d: str):
+        ent = self._docs.get(d)
+        if ent is None:
+            t = _tok(d)
+            counts = {}
+            for x in t:
+                counts[x] = counts.get(x, 0) + 1
+            ent = (counts, len(t))
+            if len(self._docs) >= self._DOC_CACHE_MAX:
+                self._docs.clear()
+            self._docs[d] = ent
+        return ent
+
     def score_batch(self, query: str, docs: List[str]) -> List[float]:
         q = set(_tok(query))
         out = []
         for d in docs:
-            t = _tok(d)
-            ov = sum(1 for x in t if x in q) / (1.0 + len(t)) if t else 0.0
+            counts, total = self._doc(d)
+            # document tokens that occur in the query, with multiplicity (an integer: counted from either side)
+            ov = sum(counts.get(x, 0) for x in q) / (1.0 + total) if total else 0.0
             h = (_seed(d, query) % 1000) / 1e6  # tiny deterministic jitter: no exact ties
             out.append(float(1.0 / (1.0 + np.exp(-(8.0 * ov - 1.0))) + h))
         return out

@@ -44,6 +44,7 @@ logger = logging.getLogger("legalrag.retrieval.hybrid_retriever")
 _CHUNK_REPR: Dict[int, Any] = {}  # id(LawChunk) -> (the chunk, repr(chunk)): see HybridRetriever._hit_text
 
 CHANNELS = ("dense", "bm25", "colbert")
+_HIT_FIELDS_SET = {"chunk", "score", "rank", "source", "score_breakdown"}
 
 
 def _minmax(scores: Sequence[float]) -> List[float]:
@@ -298,8 +299,11 @@ class HybridRetriever:
             }
             # model_construct: the fields come straight from the kernels' typed outputs and the store's own LawChunk
             # objects — the validating constructor was a third of a batch's host time (validate_python per hit)
-            out.append(RetrievalHit.model_construct(chunk=chunk_of[i], score=v[i_s], rank=r + 1, source="retriever",
-                                                    score_breakdown=sb))
+            # (every field named: model_construct otherwise resolves each missing default per hit; _fields_set = the
+            # five the validating constructor would have been given)
+            out.append(RetrievalHit.model_construct(_HIT_FIELDS_SET, chunk=chunk_of[i], score=v[i_s], rank=r + 1,
+                                                    source="retriever", semantic_score=None, graph_depth=None,
+                                                    relations=None, seed_article_id=None, score_breakdown=sb))
         return out
 
     def _eff_depth(self, top_k: int, who: str) -> int:
