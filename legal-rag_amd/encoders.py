@@ -145,9 +145,19 @@ class HashingCrossScorer:
         q = set(_tok(query))
         out = []
         for d in docs:
-            counts, total = self._doc(d)
-            # document tokens that occur in the query, with multiplicity (an integer: counted from either side)
-            ov = sum(counts.get(x, 0) for x in q) / (1.0 + total) if total else 0.0
+            head = getattr(d, "head", None)
+            if head is not None and head[-1:] == ")" and d.tail[:1] == " ":
+                # hybrid_retriever.HitText: the chunk part is shared by every hit of that chunk; the two parts meet at
+                # ") " — no token spans them, so the tokens of the whole are the tokens of the parts
+                counts, total = self._doc(head)
+                t = _tok(d.tail)
+                hit = sum(counts.get(x, 0) for x in q) + sum(1 for x in t if x in q)
+                total += len(t)
+            else:
+                counts, total = self._doc(d)
+                hit = sum(counts.get(x, 0) for x in q)
+            # `hit` = document tokens that occur in the query, with multiplicity (an integer: counted from either side)
+            ov = hit / (1.0 + total) if total else 0.0
             h = (_seed(d, query) % 1000) / 1e6  # tiny deterministic jitter: no exact ties
             out.append(float(1.0 / (1.0 + np.exp(-(8.0 * ov - 1.0))) + h))
         return out

@@ -41,6 +41,18 @@ from .rerankers import RerankerFactory, _to_doc_text
 
 logger = logging.getLogger("legalrag.retrieval.hybrid_retriever")
 
+class HitText(str):
+    """str(hit) as ONE string that also remembers its two parts: `head` ("chunk=<repr of the LawChunk>", the same str
+    object for every hit of that chunk — nearly all of the text) and `tail` (the hit's own fields).  A scorer that
+    tokenises its documents may cache per head; any other consumer sees a plain str."""
+    __slots__ = ("head", "tail")
+
+    def __new__(cls, head: str, tail: str):
+        self = super().__new__(cls, head + tail)
+        self.head, self.tail = head, tail
+        return self
+
+
 _CHUNK_REPR: Dict[int, Any] = {}  # id(LawChunk) -> (the chunk, repr(chunk)): see HybridRetriever._hit_text
 
 CHANNELS = ("dense", "bm25", "colbert")
@@ -393,10 +405,11 @@ class HybridRetriever:
         if ent is None or ent[0] is not ck:
             if len(_CHUNK_REPR) > 500_000:
                 _CHUNK_REPR.clear()
-            ent = _CHUNK_REPR[id(ck)] = (ck, repr(ck))
-        return (f"chunk={ent[1]} score={h.score!r} rank={h.rank!r} source={h.source!r} "
+            ent = _CHUNK_REPR[id(ck)] = (ck, "chunk=" + repr(ck))
+        tail = (f" score={h.score!r} rank={h.rank!r} source={h.source!r} "
                 f"semantic_score={h.semantic_score!r} graph_depth={h.graph_depth!r} relations={h.relations!r} "
                 f"seed_article_id={h.seed_article_id!r} score_breakdown={h.score_breakdown!r}")
+        return HitText(ent[1], tail)
 
     def _rerank_stage(self, questions: Sequence[str], fused_lists: List[List[RetrievalHit]], llm: Any,
                       top_k: int) -> List[List[RetrievalHit]]:

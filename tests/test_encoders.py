@@ -83,6 +83,18 @@ def test_hashing_standins_are_deterministic_unit_vectors():
     assert s[0] > s[1] and all(0 < v < 1.01 for v in s)
 
 
+def test_stand_in_cross_scorer_scores_a_hit_text_like_the_plain_string():
+    """hybrid_retriever.HitText carries str(hit) in two parts so the stand-in scorer tokenises a chunk once: the score
+    of the two-part string is the score of the same text as a plain str (fresh scorers: no shared cache)."""
+    from legal_rag_amd.retrieval.hybrid_retriever import HitText
+    head = "chunk=LawChunk(id='x', text='Sale of GOODS; the seller ΟΔΟΣ shall deliver 第一条 goods')"
+    tail = " score=0.5123 rank=1 source='retriever' score_breakdown={'channel': ['dense', 'bm25'], 'goods': 1.0}"
+    for q in ("sale goods seller", "第一条 οδος", "retriever dense rank", ""):
+        a = encoders.HashingCrossScorer().score_batch(q, [HitText(head, tail), HitText(head, tail + " goods")])
+        b = encoders.HashingCrossScorer().score_batch(q, [head + tail, head + tail + " goods"])
+        assert a == b
+
+
 def test_colbert_token_encoder_recipe(tiny):
     enc = get_token_encoder(tiny["bge"], "auto", 24)
     assert isinstance(enc, encoders.TransformersColBERT) and enc.dim == 16
