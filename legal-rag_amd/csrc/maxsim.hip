@@ -738,6 +738,13 @@ __global__ __launch_bounds__(kMsQ * 64) __attribute__((amdgpu_waves_per_eu(4, 4)
 // by as many queries as before), 3 stages = 48 KiB, three blocks per CU.
 constexpr int kMsQ2 = 4;  // waves per block; 2 queries each
 
+__device__ __forceinline__ void ms_load_query_img_hi(const unsigned char* __restrict__ img_q, int qi, int r32, int h,
+                                                     ms8h (&qh)[8]) {
+  const unsigned char* p = img_q + ((size_t)qi * 32 + r32) * 512 + 16 * h;
+#pragma unroll
+  for (int st = 0; st < 8; ++st) qh[st] = *reinterpret_cast<const ms8h*>(p + 32 * st);
+}
+
 __device__ __forceinline__ float ms_max3(float a, float b, float c) {  // max(a, b, c) in one instruction (no NaNs reach it)
   float r;
   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -747,7 +754,9 @@ __device__ __forceinline__ float ms_max3(float a, float b, float c) {  // max(a,
 template <int NBUF>
 __global__ __launch_bounds__(kMsQ2 * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void maxsim_hi2_ring_kernel(
     const unsigned char* __restrict__ img_hi, const long long* __restrict__ doc_ptr, long n_docs, int docs_per_block,
-    const float* __restrict__ Q, int nq, int q_len, float* __restrict__ approx /*[nq, n_docs]*/, float unscale_d) {
+    const float* __restrict__ Q, int nq, int q_len, float* __restrict__ approx /*[nq, n_docs]*/, float unscale_d,
+    const unsigned char* __restrict__ img_q /* nullable: the queries' split images (maxsim_split_queries_kernel) */,
+    const float* __restrict__ unscale_q) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // [NBUF][64 * 256]
   constexpr int kStage = 64 * 256;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -759,10 +768,20 @@ __global__ __launch_bounds__(kMsQ2 * 64) __attribute__((amdgpu_waves_per_eu(3, 3
   long d1 = d0 + docs_per_block;
   if (d1 > n_docs) d1 = n_docs;
 
-  ms8h qha[8], qhb[8], lo_unused[8];
+  ms8h qha[8], qhb[8];
   float unscale_a, unscale_b;
-  ms_load_query_h(Q + (size_t)(live_a ? qa : 0) * q_len * kDim, q_len, live_a, r32, h, qha, lo_unused, unscale_a);
-  ms_load_query_h(Q + (size_t)(live_b ? qb : 0) * q_len * kDim, q_len, live_b, r32, h, qhb, lo_unused, unscale_b);
+  if (img_q) {
+    // the fragments as maxsim_split_queries_kernel left them (a query is scored by n_docs / docs_per_block blocks:
+    // splitting it in each of them was 10-20 % of this kernel's vector instructions); a dead wave takes query 0's
+    ms_load_query_img_hi(img_q, live_a ? qa : 0, r32, h, qha);
+    ms_load_query_img_hi(img_q, live_b ? qb : 0, r32, h, qhb);
+    unscale_a = unscale_q[live_a ? qa : 0];
+    unscale_b = unscale_q[live_b ? qb : 0];
+  } else {
+    ms8h lo_unused[8];
+    ms_load_query_h(Q + (size_t)(live_a ? qa : 0) * q_len * kDim, q_len, live_a, r32, h, qha, lo_unused, unscale_a);
+    ms_load_query_h(Q + (size_t)(live_b ? qb : 0) * q_len * kDim, q_len, live_b, r32, h, qhb, lo_unused, unscale_b);
+  }
   unscale_a *= unscale_d;
   unscale_b *= unscale_d;
 
@@ -858,7 +877,12 @@ __global__ __launch_bounds__(kMsQ2 * 64) __attribute__((amdgpu_waves_per_eu(3, 3
       // 16 values -> 1 per query and row block as EIGHT v_max3_f32 (hipcc fused only a quarter of the fmaxf pairs: 56
       // v_max per 32 MFMAs; the pass issued ~5 other vector instructions per MFMA with its matrix pipe busy half the
       // time: 975 -> 891 us per 1 168 UCC-en queries).  Tried after it and dropped: FOUR queries per wave (64 MFMAs per
-      // tile read and barrier, 16 queries per tile, two waves per SIMD): 1.08 against 1.09 ms per hybrid step.
+      // tile read and barrier, 16 queries per tile, two waves per SIMD): 1.08 against 1.09 ms per hybrid step.  Also
+      // tried and dropped: the fragment reads of the NEXT 32-token row block issued before the current block's 32 MFMAs
+      // (the compiler's order here is two reads, s_waitcnt lgkmcnt(0), four MFMAs, eight times per tile) with a second
+      // fragment set — 64 more VGPRs, two waves per SIMD, four ring stages: 1.136 against 1.101 ms per hybrid step, slower
+      // at every block size (scripts/sweep_maxsim_docs.sh).  Neither the reads per MFMA nor their latency is what keeps
+      // the matrix pipe at half duty.
 #pragma unroll
       for (int j = 0; j < 16; j += 2) {
         best_a = ms_max3(best_a, ca[j], ca[j + 1]);
@@ -883,81 +907,133 @@ __global__ __launch_bounds__(kMsQ2 * 64) __attribute__((amdgpu_waves_per_eu(3, 3
 // zero) and stores its power-of-two unscale — the scale rule and ms_split of ms_load_query_h: identical fragments.  The
 // re-scoring pass takes a query's fragments for every (document, query) item it serves, 15 k times per UCC-en batch:
 // splitting them in the scoring wave each time cost ~500 vector instructions per item and wave.
+// `norm_sum` (nullable): the sum of the token rows' Euclidean norms, which the candidate margin of the two-pass top-k is
+// built on (maxsim_select_kernel) — the rows are in this wave's registers anyway.
 __device__ __forceinline__ void ms_split_query_wave(const float* __restrict__ Qq, int q_len, int lane,
-                                                    unsigned char* __restrict__ img, float* __restrict__ unscale) {
-  float m = 0.f;
-  for (int i = lane; i < q_len * kDim; i += 64) m = fmaxf(m, fabsf(Qq[i]));
+                                                    unsigned char* __restrict__ img, float* __restrict__ unscale,
+                                                    float* __restrict__ norm_sum = nullptr) {
+  // one pass over the query: lane holds (row, group of 8 components) g = lane + 64 it — 16 lanes per row, 4 rows per step
+  float x[8][8];
+  float m = 0.f, nsum = 0.f;
 #pragma unroll
-  for (int sft = 1; sft < 64; sft <<= 1) m = fmaxf(m, __shfl_xor(m, sft));
-  int e = 0;
-  if (m > 0.f && m <= FLT_MAX) (void)frexpf(m, &e);
-  const float sc = ldexpf(1.f, -e);
-  if (lane == 0) *unscale = ldexpf(1.f, e);
-  for (int g = lane; g < 32 * 16; g += 64) {  // (token row, group of 8 components)
-    const int row = g >> 4, grp = g & 15;
-    float x[8];
+  for (int it = 0; it < 8; ++it) {
+    const int g = lane + 64 * it, row = g >> 4, grp = g & 15;
+    float ss = 0.f;
     if (row < q_len) {
       const ms4f v0 = *reinterpret_cast<const ms4f*>(Qq + (size_t)row * kDim + 8 * grp);
       const ms4f v1 = *reinterpret_cast<const ms4f*>(Qq + (size_t)row * kDim + 8 * grp + 4);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) x[j] = v0[j], x[4 + j] = v1[j];
+      for (int j = 0; j < 4; ++j) x[it][j] = v0[j], x[it][4 + j] = v1[j];
     } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) x[j] = 0.f;
+      for (int j = 0; j < 8; ++j) x[it][j] = 0.f;
     }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      m = fmaxf(m, fabsf(x[it][j]));
+      ss += x[it][j] * x[it][j];
+    }
+#pragma unroll
+    for (int sft = 1; sft < 16; sft <<= 1) ss += __shfl_xor(ss, sft);  // the row's 16 lanes
+    nsum += sqrtf(ss);  // (every lane of the row holds it; counted once below)
+  }
+#pragma unroll
+  for (int sft = 1; sft < 64; sft <<= 1) m = fmaxf(m, __shfl_xor(m, sft));
+  nsum += __shfl_xor(nsum, 16);  // the four rows of a step sit in the four 16-lane groups
+  nsum += __shfl_xor(nsum, 32);
+  int e = 0;
+  if (m > 0.f && m <= FLT_MAX) (void)frexpf(m, &e);
+  const float sc = ldexpf(1.f, -e);
+  if (lane == 0) {
+    *unscale = ldexpf(1.f, e);
+    if (norm_sum) *norm_sum = nsum;
+  }
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int g = lane + 64 * it, row = g >> 4, grp = g & 15;
     ms8h hi, lo;
-    ms_split(x, sc, hi, lo);
+    ms_split(x[it], sc, hi, lo);
     unsigned char* dst = img + (size_t)row * 512 + 16 * grp;
     *reinterpret_cast<ms8h*>(dst) = hi;
     *reinterpret_cast<ms8h*>(dst + 256) = lo;
   }
 }
 
+// Ahead of pass 1 (round 4), one wave per query: both passes take their query fragments from these images.
+__global__ __launch_bounds__(256) void maxsim_split_queries_kernel(const float* __restrict__ Q, int nq, int q_len,
+                                                                   unsigned char* __restrict__ img_q,
+                                                                   float* __restrict__ unscale_out,
+                                                                   float* __restrict__ norm_sum) {
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= nq) return;
+  ms_split_query_wave(Q + (size_t)q * q_len * kDim, q_len, threadIdx.x & 63, img_q + (size_t)q * 32 * 512,
+                      unscale_out + q, norm_sum + q);
+}
+
 // Between the passes, one wave per query: T = the k-th best first-pass score, eps from the query's token norms, the
 // list of documents with a first-pass score >= T - 2 eps (ascending ids, at most cap; more -> overflow), and the
 // re-scored row initialised to "not a candidate".
-__global__ __launch_bounds__(128) void maxsim_select_kernel(const float* __restrict__ approx, long n_docs,
+__global__ __launch_bounds__(64) void maxsim_select_kernel(const float* __restrict__ approx, long n_docs,
                                                            const float* __restrict__ Q, int q_len, int k, int cap_sel,
                                                            float d_norm_max, float unscale_d, int cap,
                                                            float* __restrict__ exact /*[nq, n_docs]*/,
                                                            int* __restrict__ cand /*[nq, cap]*/, int* __restrict__ cnt,
                                                            int* __restrict__ overflow, int* __restrict__ dcnt,
-                                                           unsigned char* __restrict__ img_q,
-                                                           float* __restrict__ unscale_out) {
+                                                           const float* __restrict__ norm_sum /* nullable: with */,
+                                                           const float* __restrict__ unscale_in /* the split images */,
+                                                           int init_exact) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   C32* buf = reinterpret_cast<C32*>(smem);
   const int lane = threadIdx.x & 63, q = blockIdx.x;
-  if (threadIdx.x >= 64) {  // round 4: a second wave of the block splits the query for the re-scoring pass meanwhile
-    ms_split_query_wave(Q + (size_t)q * q_len * kDim, q_len, lane, img_q + (size_t)q * 32 * 512, unscale_out + q);
-    return;
-  }
   const float* row = approx + (size_t)q * n_docs;
   WaveTopK<C32> tk;
   tk.init(buf, cap_sel, k);
-  for (long base = 0; base < n_docs; base += 64) {
-    const long d = base + lane;
-    const bool v = d < n_docs;
-    tk.push_lanes(v ? C32::make(row[d], (u32)d) : C32::pad(), v, lane);
+  // T: short rows in registers (the slab top-k's selector: 47 -> ~20 us per 1 168 UCC-en queries together with the two
+  // changes below), otherwise — and on mass ties at the cut — the staged selector
+  int got = -1;
+  if (k <= 64 && n_docs <= kSelectRowsMax && cap_sel >= 128) {
+    if (n_docs <= 640)
+      got = select_row<10>(row, 0, n_docs, k, lane, tk.buf);
+    else if (n_docs <= 1280)
+      got = select_row<20>(row, 0, n_docs, k, lane, tk.buf);
+    else
+      got = select_row<32>(row, 0, n_docs, k, lane, tk.buf);
   }
-  tk.finalize(lane);
+  if (got >= 0) {
+    tk.cnt = got;
+  } else {
+    for (long base = 0; base < n_docs; base += 64) {
+      const long d = base + lane;
+      const bool v = d < n_docs;
+      tk.push_lanes(v ? C32::make(row[d], (u32)d) : C32::pad(), v, lane);
+    }
+    tk.finalize(lane);
+  }
+  wave_lds_fence();
   const float T = tk.cnt >= k ? tk.buf[k - 1].score() : -FLT_MAX;  // fewer than k documents: every one is a candidate
   wave_lds_fence();
   // eps: token norms and the query's power-of-two scale, as the scoring kernels take it
-  const float* Qq = Q + (size_t)q * q_len * kDim;
-  float nsum = 0.f, amax = 0.f;
-  for (int i = 0; i < q_len; ++i) {
-    const float a = Qq[i * kDim + lane], b = Qq[i * kDim + 64 + lane];
-    float ss = a * a + b * b;
-    amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b)));
+  float nsum = 0.f, unscale_q;
+  if (norm_sum) {  // left by maxsim_split_queries_kernel
+    nsum = norm_sum[q];
+    unscale_q = unscale_in[q];
+  } else {
+    const float* Qq = Q + (size_t)q * q_len * kDim;
+    float amax = 0.f;
+    for (int i = 0; i < q_len; ++i) {
+      const float a = Qq[i * kDim + lane], b = Qq[i * kDim + 64 + lane];
+      float ss = a * a + b * b;
+      amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b)));
 #pragma unroll
-    for (int sft = 1; sft < 64; sft <<= 1) ss += __shfl_xor(ss, sft);
-    nsum += sqrtf(ss);
+      for (int sft = 1; sft < 64; sft <<= 1) ss += __shfl_xor(ss, sft);
+      nsum += sqrtf(ss);
+    }
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) amax = fmaxf(amax, __shfl_xor(amax, sft));
+    int e = 0;
+    if (amax > 0.f && amax <= FLT_MAX) (void)frexpf(amax, &e);
+    unscale_q = ldexpf(1.f, e);
   }
-#pragma unroll
-  for (int sft = 1; sft < 64; sft <<= 1) amax = fmaxf(amax, __shfl_xor(amax, sft));
-  int e = 0;
-  if (amax > 0.f && amax <= FLT_MAX) (void)frexpf(amax, &e);
-  const float unscale_q = ldexpf(1.f, e);
   const float eps = 1.5f * 9.765625e-4f * nsum * d_norm_max * 1.0001f +
                     (float)q_len * 256.f * 2.98023224e-8f * unscale_q * unscale_d;  // + operands in fp16's subnormal range
   const float thr = (T == -FLT_MAX) ? -FLT_MAX : T - 2.f * eps;
@@ -967,7 +1043,7 @@ __global__ __launch_bounds__(128) void maxsim_select_kernel(const float* __restr
     const bool v = d < n_docs;
     const float a = v ? row[d] : 0.f;
     const bool pass = v && (a >= thr || thr == -FLT_MAX);
-    if (v) exact[(size_t)q * n_docs + d] = -FLT_MAX;
+    if (v && init_exact) exact[(size_t)q * n_docs + d] = -FLT_MAX;  // (only rowscores_topk_kernel reads whole rows)
     const unsigned long long m = __ballot(pass);
     const int at = n + __popcll(lane ? (m & (~0ull >> (64 - lane))) : 0ull);
     if (pass && at < cap) cand[(size_t)q * cap + at] = (int)d;
@@ -978,10 +1054,8 @@ __global__ __launch_bounds__(128) void maxsim_select_kernel(const float* __restr
     cnt[q] = n > cap ? 0 : n;
   }
   if (dcnt != nullptr && n <= cap) {  // round 4: the re-scoring pass walks the pairs by document
-    for (long base = 0; base < n_docs; base += 64) {
-      const long d = base + lane;
-      if (d < n_docs && (row[d] >= thr || thr == -FLT_MAX)) atomicAdd(dcnt + d, 1);
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's own list, just written
+    for (int j = lane; j < n; j += 64) atomicAdd(dcnt + cand[(size_t)q * cap + j], 1);
   }
 }
 
@@ -1121,36 +1195,43 @@ __global__ __launch_bounds__(256) void maxsim_doc_offsets_kernel(const int* __re
                                                                  const long long* __restrict__ doc_ptr,
                                                                  int* __restrict__ doff, int* __restrict__ ioff,
                                                                  MsItem* __restrict__ items) {
-  __shared__ int part[2][256];
+  __shared__ int wsum[2][4];
   __shared__ int bucket[16], bpos[16];
   if (threadIdx.x < 16) bucket[threadIdx.x] = 0;
   __syncthreads();
+  // exclusive prefix sums of (pairs, items) over the documents, 256 documents per step: an inclusive scan inside each
+  // wave on shuffles, the four wave totals through LDS — two barriers per step (the 8-step LDS scan of round 4's first
+  // version took 16; the kernel is a single block between two launches that wait for it)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int carry_p = 0, carry_i = 0;
   for (long base = 0; base < n_docs; base += 256) {
     const long i = base + threadIdx.x;
     const int v = i < n_docs ? dcnt[i] : 0;
     const int it = (v + kMsQ - 1) / kMsQ;
-    part[0][threadIdx.x] = v;
-    part[1][threadIdx.x] = it;
+    int sp = v, si = it;
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) {
+      const int op = __shfl_up(sp, sft), oi = __shfl_up(si, sft);
+      if (lane >= sft) sp += op, si += oi;
+    }
+    if (lane == 63) wsum[0][wave] = sp, wsum[1][wave] = si;
     __syncthreads();
-    for (int sft = 1; sft < 256; sft <<= 1) {
-      const int o0 = threadIdx.x >= sft ? part[0][threadIdx.x - sft] : 0;
-      const int o1 = threadIdx.x >= sft ? part[1][threadIdx.x - sft] : 0;
-      __syncthreads();
-      part[0][threadIdx.x] += o0;
-      part[1][threadIdx.x] += o1;
-      __syncthreads();
+    int bp = 0, bi = 0, tp = 0, ti = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w < wave) bp += wsum[0][w], bi += wsum[1][w];
+      tp += wsum[0][w], ti += wsum[1][w];
     }
     if (i < n_docs) {
-      doff[i] = carry_p + part[0][threadIdx.x] - v;
-      ioff[i] = carry_i + part[1][threadIdx.x] - it;
+      doff[i] = carry_p + bp + sp - v;
+      ioff[i] = carry_i + bi + si - it;
       if (it) {  // items per cost class: a document's items cost its tiles (longest first below)
         const int tiles = (int)((doc_ptr[i + 1] - doc_ptr[i] + 31) >> 5);
         atomicAdd(&bucket[15 - (tiles < 15 ? tiles : 15)], it);
       }
     }
-    carry_p += part[0][255];
-    carry_i += part[1][255];
+    carry_p += tp;
+    carry_i += ti;
     __syncthreads();
   }
   if (threadIdx.x == 0) {
@@ -1343,6 +1424,56 @@ __global__ __launch_bounds__(256) void rowscores_topk_kernel(const float* __rest
   }
 }
 
+// The two-pass top-k's last step, one wave per query: only a query's candidates (<= cap, 64 for k <= 32) carry a
+// re-scored value, so the k best are found among THEM — one register sort — instead of scanning the n_docs-long row that
+// the select kernel had to fill with -FLT_MAX first (rowscores_topk_kernel: 18 us per 1 168 UCC-en queries, + 591 stores per
+// query in the select kernel).  A query whose candidate list overflowed was re-scored in full (maxsim_overflow_kernel):
+// its whole row is ranked.  Same keys (score, lower id first), same result.
+__global__ __launch_bounds__(256) void maxsim_final_topk_kernel(const float* __restrict__ exact, long n_docs, int nq,
+                                                                 const int* __restrict__ cand, const int* __restrict__ cnt,
+                                                                 const int* __restrict__ overflow, int cap, int k,
+                                                                 int cap_sel, float* __restrict__ out_scores,
+                                                                 long long* __restrict__ out_ids) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = blockIdx.x * 4 + wave;
+  if (q >= nq) return;
+  const float* row = exact + (size_t)q * n_docs;
+  const bool whole = overflow[q] != 0;
+  const int n = whole ? 0 : cnt[q];
+  if (!whole && cap <= 64 && k <= 64) {
+    C32 c = C32::pad();
+    if (lane < n) {
+      const int d = cand[(size_t)q * cap + lane];
+      c = C32::make(row[d], (u32)d);
+    }
+    c = wave_sort64_desc(c, lane);
+    if (lane < k) {
+      const bool v = lane < n;
+      out_scores[(size_t)q * k + lane] = v ? c.score() : -FLT_MAX;
+      out_ids[(size_t)q * k + lane] = v ? c.id() : -1ll;
+    }
+    return;
+  }
+  WaveTopK<C32> tk;
+  tk.init(reinterpret_cast<C32*>(smem) + (size_t)wave * cap_sel, cap_sel, k);
+  const long total = whole ? n_docs : (long)n;
+  for (long base = 0; base < total; base += 64) {
+    const long i = base + lane;
+    const bool v = i < total;
+    long d = 0;
+    if (v) d = whole ? i : (long)cand[(size_t)q * cap + i];
+    tk.push_lanes(v ? C32::make(row[d], (u32)d) : C32::pad(), v, lane);
+  }
+  tk.finalize(lane);
+  for (int j = lane; j < k; j += 64) {
+    const bool v = j < tk.cnt;
+    const C32 c = v ? tk.buf[j] : C32::pad();
+    out_scores[(size_t)q * k + j] = v ? c.score() : -FLT_MAX;
+    out_ids[(size_t)q * k + j] = v ? c.id() : -1ll;
+  }
+}
+
 }  // namespace amdr
 
 using namespace amdr;
@@ -1386,7 +1517,7 @@ size_t ms_workspace_bytes(const amdr_maxsim* h, int nq, int k, bool want_topk) {
   return 2 * rows + ((size_t)nq * ms_cand_cap(k) + 3 * (size_t)nq + 1) * sizeof(int) + 256 +
          ((size_t)nq * ms_cand_cap(k) + 4 * (size_t)h->n_docs + 8) * sizeof(int) +
          ((size_t)h->n_docs + (size_t)nq * ms_cand_cap(k) / kMsQ + 8) * sizeof(MsItem) +
-         (size_t)nq * (32 * 512 + sizeof(float)) + 512;  // + the split image of the queries and their scales
+         (size_t)nq * (32 * 512 + 2 * sizeof(float)) + 512;  // + the split image of the queries, their scales, norm sums
 }
 
 int ms_run(amdr_maxsim* h, const float* Q_dev, int nq, int q_len, int k, float* full_dev, float* scores_dev,
@@ -1403,23 +1534,6 @@ int ms_run(amdr_maxsim* h, const float* Q_dev, int nq, int q_len, int k, float* 
     int* cand = reinterpret_cast<int*>(wsb + 2 * rows);
     int* cnt = cand + (size_t)nq * cap;
     int* ovf = cnt + nq;
-    const char* dpb = getenv("AMDR_MAXSIM_DOCS");  // documents per block of pass 1 (UCC-en 16 / 32 / 64 / 128: 1.05 / 1.07 / 1.11 /
-    long docs = dpb && atoi(dpb) > 0 ? atoi(dpb) : 64;  // 1.10 ms; Civil-Code-zh 32 / 64 / 128: 1.48 / 1.28 / 1.28 ms)
-    while (ceil_div(h->n_docs, docs) > 65535) docs *= 2;
-    const char* h2 = getenv("AMDR_MAXSIM_HI2");  // "0": one query per wave (A/B)
-    if (h2 && h2[0] == '0') {
-      AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_hi_ring_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   4 * 16384));
-      hipLaunchKernelGGL((maxsim_hi_ring_kernel<4>), dim3(ceil_div(nq, kMsQ), ceil_div(h->n_docs, docs)), dim3(kMsQ * 64),
-                         4 * 16384, st, h->img_hi, h->doc_ptr, (long)h->n_docs, (int)docs, Q_dev, nq, q_len, approx,
-                         unscale_d);
-    } else {
-      AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_hi2_ring_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   3 * 16384));
-      hipLaunchKernelGGL((maxsim_hi2_ring_kernel<3>), dim3(ceil_div(nq, 2 * kMsQ2), ceil_div(h->n_docs, docs)),
-                         dim3(kMsQ2 * 64), 3 * 16384, st, h->img_hi, h->doc_ptr, (long)h->n_docs, (int)docs, Q_dev, nq,
-                         q_len, approx, unscale_d);
-    }
     const int cap_sel = topk_cap(k);
     int* off = ovf + nq;                      // [nq + 1] (round-3 form)
     int* pairs = off + nq + 1;                // round 4: [nq * cap] queries, grouped by document
@@ -1431,12 +1545,40 @@ int ms_run(amdr_maxsim* h, const float* Q_dev, int nq, int q_len, int k, float* 
     unsigned char* img_q = reinterpret_cast<unsigned char*>(
         ((uintptr_t)(items + h->n_docs + (size_t)nq * cap / kMsQ + 8) + 255) & ~(uintptr_t)255);
     float* unscale_q = reinterpret_cast<float*>(img_q + (size_t)nq * 32 * 512);
+    float* nsum_q = unscale_q + nq;
     const char* rs = getenv("AMDR_MAXSIM_RESCORE");  // "0": one wave per pair (the round-3 form; A/B, tests)
     const bool by_doc = !(rs && rs[0] == '0');
+    // documents per block of pass 1 (round 4, scripts/sweep_maxsim_docs.sh, ms per hybrid step: UCC-en 8 / 16 / 32 / 64 /
+    // 128: 1.056 / 1.035 / 1.027 / 1.080 / 1.064; the Civil-Code-zh channel 1.28 / 1.21 / 1.18 / 1.17 / 1.18)
+    const char* fc = getenv("AMDR_MAXSIM_FINAL");  // "0": rank the whole re-scored rows (rowscores_topk_kernel; A/B, tests)
+    const bool final_cand = !(fc && fc[0] == '0');
+    const char* dpb = getenv("AMDR_MAXSIM_DOCS");
+    long docs = dpb && atoi(dpb) > 0 ? atoi(dpb) : 32;
+    while (ceil_div(h->n_docs, docs) > 65535) docs *= 2;
+    if (by_doc)
+      hipLaunchKernelGGL(maxsim_split_queries_kernel, dim3(ceil_div(nq, 4)), dim3(256), 0, st, Q_dev, nq, q_len, img_q,
+                         unscale_q, nsum_q);
+    const char* h2 = getenv("AMDR_MAXSIM_HI2");  // "0": one query per wave (A/B)
+    if (h2 && h2[0] == '0') {
+      AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_hi_ring_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   4 * 16384));
+      hipLaunchKernelGGL((maxsim_hi_ring_kernel<4>), dim3(ceil_div(nq, kMsQ), ceil_div(h->n_docs, docs)), dim3(kMsQ * 64),
+                         4 * 16384, st, h->img_hi, h->doc_ptr, (long)h->n_docs, (int)docs, Q_dev, nq, q_len, approx,
+                         unscale_d);
+    } else {
+      const char* ps = getenv("AMDR_MAXSIM_PRESPLIT");  // "0": every block of pass 1 splits its queries itself (A/B)
+      const bool presplit = by_doc && !(ps && ps[0] == '0');
+      AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_hi2_ring_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   3 * 16384));
+      hipLaunchKernelGGL((maxsim_hi2_ring_kernel<3>), dim3(ceil_div(nq, 2 * kMsQ2), ceil_div(h->n_docs, docs)),
+                         dim3(kMsQ2 * 64), 3 * 16384, st, h->img_hi, h->doc_ptr, (long)h->n_docs, (int)docs, Q_dev, nq,
+                         q_len, approx, unscale_d, presplit ? img_q : (const unsigned char*)nullptr, unscale_q);
+    }
     if (by_doc) AMDR_HIP(hipMemsetAsync(dcnt, 0, 2 * (size_t)h->n_docs * sizeof(int), st));
-    hipLaunchKernelGGL(maxsim_select_kernel, dim3(nq), dim3(by_doc ? 128 : 64), (size_t)cap_sel * sizeof(C32), st, approx,
+    hipLaunchKernelGGL(maxsim_select_kernel, dim3(nq), dim3(64), (size_t)cap_sel * sizeof(C32), st, approx,
                        (long)h->n_docs, Q_dev, q_len, k, cap_sel, h->d_norm_max, unscale_d, cap, exact, cand, cnt, ovf,
-                       by_doc ? dcnt : (int*)nullptr, img_q, unscale_q);
+                       by_doc ? dcnt : (int*)nullptr, by_doc ? nsum_q : (const float*)nullptr, unscale_q,
+                       final_cand ? 0 : 1);
     constexpr int kPairLds = kMsWaves * 16384;
     AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_overflow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds));
     int dev = 0, cus = 256;
@@ -1460,6 +1602,12 @@ int ms_run(amdr_maxsim* h, const float* Q_dev, int nq, int q_len, int k, float* 
     hipLaunchKernelGGL(maxsim_overflow_kernel, dim3(nq), dim3(256), kPairLds, st, h->img, h->doc_ptr, (long)h->n_docs,
                        Q_dev, q_len, unscale_d, ovf, exact);
     AMDR_HIP(hipGetLastError());
+    if (final_cand) {
+      hipLaunchKernelGGL(maxsim_final_topk_kernel, dim3(ceil_div(nq, 4)), dim3(256), (size_t)4 * cap_sel * sizeof(C32), st,
+                         exact, (long)h->n_docs, nq, cand, cnt, ovf, cap, k, cap_sel, scores_dev, (long long*)ids_dev);
+      AMDR_HIP(hipGetLastError());
+      return AMDR_OK;
+    }
     full_dev = exact;  // the final top-k ranks the re-scored rows
   } else if (batch && half) {
     const char* rg = getenv("AMDR_MAXSIM_RING");  // LDS stages (2 / 3 / 4 / 6; measured best: 4)

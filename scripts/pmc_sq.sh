@@ -17,5 +17,10 @@ run() { # name, counters...
 }
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE
 run sq2 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES
+if [ -n "$EXTRA" ]; then  # latency / back-pressure counters (LEVEL / INSTS = mean cycles in flight per instruction)
+run sq3 SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_MFMA
+run sq4 SQ_VALU_MFMA_COEXEC_CYCLES SQ_LEVEL_WAVES SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT
+run sq5 SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_IFETCH_LEVEL SQ_IFETCH SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM
+fi
 cat $O/progress.log
-grep -h "$FILT\|kernel |" $O/sq1.md $O/sq2.md | head -40
+grep -h "$FILT\|kernel |" $O/sq*.md | head -${LINES:-40}

@@ -670,14 +670,19 @@ def test_maxsim_two_pass_topk_equals_one_pass(nat, monkeypatch):
         out = {}
         # "1": two passes, the candidates re-scored by document (round 4: a block = one document x 8 of its queries);
         # "1r3": two passes, one wave per candidate pair (round 3); "0": one pass
-        for flag, rescore in (("1", "1"), ("1r3", "0"), ("0", "1")):
+        # "1w": as "1" with the round-4 shortcuts off — every block of pass 1 splits its own queries, the final top-k
+        # ranks whole re-scored rows
+        for flag, rescore, short in (("1", "1", "1"), ("1r3", "0", "1"), ("0", "1", "1"), ("1w", "1", "0")):
             monkeypatch.setenv("AMDR_MAXSIM_TWOPASS", flag[0])
             monkeypatch.setenv("AMDR_MAXSIM_RESCORE", rescore)
+            monkeypatch.setenv("AMDR_MAXSIM_PRESPLIT", short)
+            monkeypatch.setenv("AMDR_MAXSIM_FINAL", short)
             idx = nat.MaxSimIndex(D, doc_ptr)
             out[flag] = idx.search(Q, k)
             idx.close()
-        monkeypatch.delenv("AMDR_MAXSIM_RESCORE")
-        for other in ("0", "1r3"):
+        for name in ("AMDR_MAXSIM_RESCORE", "AMDR_MAXSIM_PRESPLIT", "AMDR_MAXSIM_FINAL"):
+            monkeypatch.delenv(name)
+        for other in ("0", "1r3", "1w"):
             assert np.array_equal(out["1"][1], out[other][1]), (k, other)
             assert np.array_equal(out["1"][0], out[other][0]), (k, other)
         return out["1"]
