@@ -979,6 +979,7 @@ __global__ __launch_bounds__(64) void maxsim_select_kernel(const float* __restri
                                                            float* __restrict__ exact /*[nq, n_docs]*/,
                                                            int* __restrict__ cand /*[nq, cap]*/, int* __restrict__ cnt,
                                                            int* __restrict__ overflow, int* __restrict__ dcnt,
+                                                           int* __restrict__ dlist /*[n_docs][nq]*/, int nq,
                                                            const float* __restrict__ norm_sum /* nullable: with */,
                                                            const float* __restrict__ unscale_in /* the split images */,
                                                            int init_exact) {
@@ -1053,9 +1054,14 @@ __global__ __launch_bounds__(64) void maxsim_select_kernel(const float* __restri
     overflow[q] = n > cap ? 1 : 0;
     cnt[q] = n > cap ? 0 : n;
   }
-  if (dcnt != nullptr && n <= cap) {  // round 4: the re-scoring pass walks the pairs by document
+  if (dcnt != nullptr && n <= cap) {
+    // round 4: the re-scoring pass walks the pairs BY DOCUMENT — the query joins the list of each of its candidates
+    // (row d of dlist, one slot per query at most: no offsets to compute, no second pass to fill them)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's own list, just written
-    for (int j = lane; j < n; j += 64) atomicAdd(dcnt + cand[(size_t)q * cap + j], 1);
+    for (int j = lane; j < n; j += 64) {
+      const int d = cand[(size_t)q * cap + j];
+      dlist[(size_t)d * nq + atomicAdd(dcnt + d, 1)] = q;  // the order inside a document's list does not matter
+    }
   }
 }
 
@@ -1183,71 +1189,44 @@ __device__ __forceinline__ void ms_load_query_img(const unsigned char* __restric
 // the pairs are inverted to per-document query lists and a block takes (document, 8 of its queries): the document's
 // tiles go ONCE through the block's LDS ring (the one-pass ring kernel's, same fragments, same tile function: the same
 // bits) and feed 8 queries' MFMAs.
-//   maxsim_select_kernel        also counts the candidates of every document (dcnt)
-//   maxsim_doc_offsets_kernel   exclusive prefix sums over the documents: pairs (doff) and 8-query items (ioff)
-//   maxsim_pairs_fill_kernel    pairs[doff[doc] + slot] = query
+//   maxsim_select_kernel        also appends the query to the list of each of its candidate documents (dlist, dcnt)
+//   maxsim_items_kernel         the item table, longest documents first (the first version of this round also
+//                               prefix-summed per-document offsets and filled a packed pair list with a third kernel:
+//                               fixed-stride lists written by the select kernel itself took both away)
 //   maxsim_rescore_ring_kernel  persistent blocks of 8 waves walk the items
 struct MsItem {  // one unit of the re-scoring pass: a document (its token range) and up to 8 of its queries
   int doc, p0, cnt, len;
   long long t_lo, pad;
 };
-__global__ __launch_bounds__(256) void maxsim_doc_offsets_kernel(const int* __restrict__ dcnt, long n_docs,
-                                                                 const long long* __restrict__ doc_ptr,
-                                                                 int* __restrict__ doff, int* __restrict__ ioff,
-                                                                 MsItem* __restrict__ items) {
-  __shared__ int wsum[2][4];
+__global__ __launch_bounds__(256) void maxsim_items_kernel(const int* __restrict__ dcnt, long n_docs,
+                                                           const long long* __restrict__ doc_ptr,
+                                                           int* __restrict__ n_items, MsItem* __restrict__ items) {
   __shared__ int bucket[16], bpos[16];
   if (threadIdx.x < 16) bucket[threadIdx.x] = 0;
   __syncthreads();
-  // exclusive prefix sums of (pairs, items) over the documents, 256 documents per step: an inclusive scan inside each
-  // wave on shuffles, the four wave totals through LDS — two barriers per step (the 8-step LDS scan of round 4's first
-  // version took 16; the kernel is a single block between two launches that wait for it)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int carry_p = 0, carry_i = 0;
-  for (long base = 0; base < n_docs; base += 256) {
-    const long i = base + threadIdx.x;
-    const int v = i < n_docs ? dcnt[i] : 0;
-    const int it = (v + kMsQ - 1) / kMsQ;
-    int sp = v, si = it;
-#pragma unroll
-    for (int sft = 1; sft < 64; sft <<= 1) {
-      const int op = __shfl_up(sp, sft), oi = __shfl_up(si, sft);
-      if (lane >= sft) sp += op, si += oi;
+  // items per cost class: a document's items (8 of its queries each) cost its tiles
+  for (long i = threadIdx.x; i < n_docs; i += 256) {
+    const int it = (dcnt[i] + kMsQ - 1) / kMsQ;
+    if (it) {
+      const int tiles = (int)((doc_ptr[i + 1] - doc_ptr[i] + 31) >> 5);
+      atomicAdd(&bucket[15 - (tiles < 15 ? tiles : 15)], it);
     }
-    if (lane == 63) wsum[0][wave] = sp, wsum[1][wave] = si;
-    __syncthreads();
-    int bp = 0, bi = 0, tp = 0, ti = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      if (w < wave) bp += wsum[0][w], bi += wsum[1][w];
-      tp += wsum[0][w], ti += wsum[1][w];
-    }
-    if (i < n_docs) {
-      doff[i] = carry_p + bp + sp - v;
-      ioff[i] = carry_i + bi + si - it;
-      if (it) {  // items per cost class: a document's items cost its tiles (longest first below)
-        const int tiles = (int)((doc_ptr[i + 1] - doc_ptr[i] + 31) >> 5);
-        atomicAdd(&bucket[15 - (tiles < 15 ? tiles : 15)], it);
-      }
-    }
-    carry_p += tp;
-    carry_i += ti;
-    __syncthreads();
   }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    doff[n_docs] = carry_p;
-    ioff[n_docs] = carry_i;
     int at = 0;
     for (int c = 0; c < 16; ++c) {
       bpos[c] = at;
       at += bucket[c];
     }
+    *n_items = at;
   }
   __syncthreads();
   // The item table, LONGEST DOCUMENTS FIRST (a counting sort over the tile count): the re-scoring blocks take items
   // b, b + grid, b + 2 grid, ... — dealt from a descending order every block's share costs about the same.  In document
   // order a block's 4-5 items ranged from 1 to 7 tiles each and the waves were alive for 65 % of the launch (SQ_WAVE_CYCLES).
-  // One 32-byte descriptor per item: a block reads it instead of searching the offsets.
+  // One 32-byte descriptor per item (p0 = its first slot in the document's query list): a block reads it instead of
+  // searching offsets.
   for (long i = threadIdx.x; i < n_docs; i += 256) {
     const int v = dcnt[i];
     const int it = (v + kMsQ - 1) / kMsQ;
@@ -1256,28 +1235,17 @@ __global__ __launch_bounds__(256) void maxsim_doc_offsets_kernel(const int* __re
     const int len = (int)(doc_ptr[i + 1] - t_lo);
     const int tiles = (len + 31) >> 5;
     const int at = atomicAdd(&bpos[15 - (tiles < 15 ? tiles : 15)], it);
-    const int p0 = doff[i];
     for (int c = 0; c < it; ++c)
-      items[at + c] = MsItem{(int)i, p0 + c * kMsQ, v - c * kMsQ < kMsQ ? v - c * kMsQ : kMsQ, len, t_lo, 0};
+      items[at + c] = MsItem{(int)i, c * kMsQ, v - c * kMsQ < kMsQ ? v - c * kMsQ : kMsQ, len, t_lo, 0};
   }
-}
-
-__global__ __launch_bounds__(256) void maxsim_pairs_fill_kernel(const int* __restrict__ cand, const int* __restrict__ cnt,
-                                                                int nq, int cap, const int* __restrict__ doff,
-                                                                int* __restrict__ dfill, int* __restrict__ pairs) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long)nq * cap) return;
-  const int q = (int)(idx / cap), j = (int)(idx - (long)q * cap);
-  if (j >= cnt[q]) return;
-  const int doc = cand[idx];
-  pairs[doff[doc] + atomicAdd(dfill + doc, 1)] = q;  // the order inside a document's list does not matter
 }
 
 template <int NBUF>
 __global__ __launch_bounds__(kMsQ * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void maxsim_rescore_ring_kernel(
     const unsigned char* __restrict__ img, long n_docs, const unsigned char* __restrict__ img_q,
     const float* __restrict__ unscale_q, int q_len, float unscale_d, const MsItem* __restrict__ item_tab,
-    const int* __restrict__ ioff, const int* __restrict__ pairs, float* __restrict__ exact /*[nq, n_docs]*/) {
+    const int* __restrict__ n_items, const int* __restrict__ dlist /*[n_docs][nq]: a document's queries*/, int nq,
+    float* __restrict__ exact /*[nq, n_docs]*/) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // [NBUF][32 * 512]
   constexpr int kStage = 32 * 512;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1292,7 +1260,7 @@ __global__ __launch_bounds__(kMsQ * 64) __attribute__((amdgpu_waves_per_eu(4, 4)
   int foff[8];
 #pragma unroll
   for (int st = 0; st < 8; ++st) foff[st] = ms_tile_off(r32, 2 * st + h);
-  const int items = ioff[n_docs];
+  const int items = *n_items;
   const int stride = (int)gridDim.x;
   auto desc_of = [&](int it) { return it < items ? item_tab[it] : MsItem{0, 0, 0, 0, 0, 0}; };
   // The block's items (blockIdx.x, + gridDim.x, ...) are ONE stream of tiles through the ring: the producer cursor runs up
@@ -1300,7 +1268,7 @@ __global__ __launch_bounds__(kMsQ * 64) __attribute__((amdgpu_waves_per_eu(4, 4)
   // exposed a memory latency per item and left the ring mostly empty).  Consumer look-ahead: the descriptor of the item
   // after next and this wave's query of the next item are requested while the current item is multiplied.
   MsItem c_cur = desc_of(blockIdx.x), c_nxt = desc_of(blockIdx.x + stride);
-  int qi_c = wave < c_cur.cnt ? pairs[c_cur.p0 + wave] : 0;
+  int qi_c = wave < c_cur.cnt ? dlist[(size_t)c_cur.doc * nq + c_cur.p0 + wave] : 0;
   MsItem p_cur = c_cur, p_nxt = c_nxt;
   int p_item = blockIdx.x, p_tile = 0;
   int issued = 0, done = 0;
@@ -1333,7 +1301,7 @@ __global__ __launch_bounds__(kMsQ * 64) __attribute__((amdgpu_waves_per_eu(4, 4)
     asm volatile("" ::: "memory");
     const int safe = issued;  // tiles below this index need no further wait by this wave
     const MsItem nn = desc_of(item + 2 * stride);
-    const int qi_n = wave < c_nxt.cnt ? pairs[c_nxt.p0 + wave] : 0;
+    const int qi_n = wave < c_nxt.cnt ? dlist[(size_t)c_nxt.doc * nq + c_nxt.p0 + wave] : 0;
     float best = -FLT_MAX;
     for (int t = 0; t < ntiles; ++t) {
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the fragment reads of the previous tile
@@ -1512,9 +1480,9 @@ int ms_cand_cap(int k) {
 size_t ms_workspace_bytes(const amdr_maxsim* h, int nq, int k, bool want_topk) {
   const size_t rows = ((size_t)nq * h->n_docs * sizeof(float) + 255) / 256 * 256;
   if (!ms_two_pass(h, nq, k, want_topk)) return rows;
-  // + the by-document pair lists of the re-scoring pass: pairs [nq * cap], dcnt / dfill [n_docs] each, doff / ioff
-  // [n_docs + 1], the item table (<= n_docs + pairs / 8 descriptors of 16 bytes)
-  return 2 * rows + ((size_t)nq * ms_cand_cap(k) + 3 * (size_t)nq + 1) * sizeof(int) + 256 +
+  // three row blocks (first-pass scores, re-scored scores, the per-document query lists of the re-scoring pass) + the
+  // candidate lists [nq * cap], counters, the item table (<= n_docs + pairs / 8 descriptors of 32 bytes); an upper bound
+  return 3 * rows + ((size_t)nq * ms_cand_cap(k) + 3 * (size_t)nq + 1) * sizeof(int) + 256 +  // (3rd: dlist [n_docs][nq])
          ((size_t)nq * ms_cand_cap(k) + 4 * (size_t)h->n_docs + 8) * sizeof(int) +
          ((size_t)h->n_docs + (size_t)nq * ms_cand_cap(k) / kMsQ + 8) * sizeof(MsItem) +
          (size_t)nq * (32 * 512 + 2 * sizeof(float)) + 512;  // + the split image of the queries, their scales, norm sums
@@ -1531,17 +1499,15 @@ int ms_run(amdr_maxsim* h, const float* Q_dev, int nq, int q_len, int k, float* 
     float* approx = full_dev;
     float* exact = reinterpret_cast<float*>(wsb + rows);
     const int cap = ms_cand_cap(k);
-    int* cand = reinterpret_cast<int*>(wsb + 2 * rows);
+    int* dlist = reinterpret_cast<int*>(wsb + 2 * rows);  // [n_docs][nq] the queries a document is a candidate of
+    int* cand = reinterpret_cast<int*>(wsb + 3 * rows);
     int* cnt = cand + (size_t)nq * cap;
     int* ovf = cnt + nq;
     const int cap_sel = topk_cap(k);
     int* off = ovf + nq;                      // [nq + 1] (round-3 form)
-    int* pairs = off + nq + 1;                // round 4: [nq * cap] queries, grouped by document
-    int* dcnt = pairs + (size_t)nq * cap;     // [n_docs] candidates per document, then dfill [n_docs]
-    int* dfill = dcnt + h->n_docs;
-    int* doff = dfill + h->n_docs;            // [n_docs + 1] first pair of a document
-    int* ioff = doff + h->n_docs + 1;         // [n_docs + 1] first 8-query item of a document
-    MsItem* items = reinterpret_cast<MsItem*>(((uintptr_t)(ioff + h->n_docs + 1) + 31) & ~(uintptr_t)31);
+    int* dcnt = off + nq + 1;                 // round 4: [n_docs] candidates per document
+    int* ioff = dcnt + h->n_docs;             // [1] items of the re-scoring pass
+    MsItem* items = reinterpret_cast<MsItem*>(((uintptr_t)(ioff + 1) + 31) & ~(uintptr_t)31);
     unsigned char* img_q = reinterpret_cast<unsigned char*>(
         ((uintptr_t)(items + h->n_docs + (size_t)nq * cap / kMsQ + 8) + 255) & ~(uintptr_t)255);
     float* unscale_q = reinterpret_cast<float*>(img_q + (size_t)nq * 32 * 512);
@@ -1574,10 +1540,10 @@ int ms_run(amdr_maxsim* h, const float* Q_dev, int nq, int q_len, int k, float* 
                          dim3(kMsQ2 * 64), 3 * 16384, st, h->img_hi, h->doc_ptr, (long)h->n_docs, (int)docs, Q_dev, nq,
                          q_len, approx, unscale_d, presplit ? img_q : (const unsigned char*)nullptr, unscale_q);
     }
-    if (by_doc) AMDR_HIP(hipMemsetAsync(dcnt, 0, 2 * (size_t)h->n_docs * sizeof(int), st));
+    if (by_doc) AMDR_HIP(hipMemsetAsync(dcnt, 0, (size_t)h->n_docs * sizeof(int), st));
     hipLaunchKernelGGL(maxsim_select_kernel, dim3(nq), dim3(64), (size_t)cap_sel * sizeof(C32), st, approx,
                        (long)h->n_docs, Q_dev, q_len, k, cap_sel, h->d_norm_max, unscale_d, cap, exact, cand, cnt, ovf,
-                       by_doc ? dcnt : (int*)nullptr, by_doc ? nsum_q : (const float*)nullptr, unscale_q,
+                       by_doc ? dcnt : (int*)nullptr, dlist, nq, by_doc ? nsum_q : (const float*)nullptr, unscale_q,
                        final_cand ? 0 : 1);
     constexpr int kPairLds = kMsWaves * 16384;
     AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_overflow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds));
@@ -1585,14 +1551,11 @@ int ms_run(amdr_maxsim* h, const float* Q_dev, int nq, int q_len, int k, float* 
     AMDR_HIP(hipGetDevice(&dev));
     AMDR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     if (by_doc) {
-      hipLaunchKernelGGL(maxsim_doc_offsets_kernel, dim3(1), dim3(256), 0, st, dcnt, (long)h->n_docs, h->doc_ptr, doff, ioff,
-                         items);
-      hipLaunchKernelGGL(maxsim_pairs_fill_kernel, dim3(ceil_div((long)nq * cap, 256)), dim3(256), 0, st, cand, cnt, nq, cap,
-                         doff, dfill, pairs);
+      hipLaunchKernelGGL(maxsim_items_kernel, dim3(1), dim3(256), 0, st, dcnt, (long)h->n_docs, h->doc_ptr, ioff, items);
       AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_rescore_ring_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    4 * 16384));
       hipLaunchKernelGGL((maxsim_rescore_ring_kernel<4>), dim3(2 * cus), dim3(kMsQ * 64), 4 * 16384, st, h->img,
-                         (long)h->n_docs, img_q, unscale_q, q_len, unscale_d, items, ioff, pairs, exact);
+                         (long)h->n_docs, img_q, unscale_q, q_len, unscale_d, items, ioff, dlist, nq, exact);
     } else {
       AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_rescore_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds));
       hipLaunchKernelGGL(maxsim_offsets_kernel, dim3(1), dim3(256), 0, st, cnt, nq, off);

@@ -52,12 +52,12 @@ OBJECTS = {
                         ("dense_only_d384", "tiled_batch", "roofline", "plan")),
     "ucc_colbert": (["bench.py", "--only", "ucc_colbert", "--steps", "5"],
                     ["maxsim_hi2_ring_kernel", "maxsim_select_kernel", "maxsim_rescore_ring_kernel", "maxsim_rescore_kernel",
-                     "maxsim_pairs_fill_kernel", "maxsim_doc_offsets_kernel", "maxsim_split_queries_kernel"],
+                     "maxsim_items_kernel", "maxsim_split_queries_kernel", "maxsim_final_topk_kernel"],
                     ("ucc_colbert", "roofline", "kernel")),
     "full_hybrid_rerank": (["bench.py", "--only", "full_hybrid_rerank", "--steps", "5"],
                            ["maxsim_hi2_ring_kernel", "maxsim_select_kernel", "maxsim_rescore_ring_kernel",
-                            "maxsim_rescore_kernel", "maxsim_pairs_fill_kernel", "maxsim_doc_offsets_kernel",
-                            "maxsim_split_queries_kernel"], ("full_hybrid_rerank", "roofline", "kernel")),
+                            "maxsim_rescore_kernel", "maxsim_items_kernel", "maxsim_split_queries_kernel",
+                            "maxsim_final_topk_kernel"], ("full_hybrid_rerank", "roofline", "kernel")),
     "synth10m_b1": (["scripts/run_dense_once.py", "10000000", "1", "768", "3"], ["dense_scan_topk_kernel"], None),
     "synth10m_b4": (["scripts/run_dense_once.py", "10000000", "4", "768", "3"], ["dense_scan_topk_kernel"], None),
     "synth10m_b8": (["scripts/run_dense_once.py", "10000000", "8", "768", "3"], ["dense_hi_tilemax_kernel<12, true>"], None),
