@@ -752,7 +752,7 @@ __device__ __forceinline__ float ms_max3(float a, float b, float c) {  // max(a,
 }
 
 template <int NBUF>
-__global__ __launch_bounds__(kMsQ2 * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void maxsim_hi2_ring_kernel(
+__global__ __launch_bounds__(kMsQ2 * 64) __attribute__((amdgpu_waves_per_eu(3, NBUF == 2 ? 5 : 3))) void maxsim_hi2_ring_kernel(
     const unsigned char* __restrict__ img_hi, const long long* __restrict__ doc_ptr, long n_docs, int docs_per_block,
     const float* __restrict__ Q, int nq, int q_len, float* __restrict__ approx /*[nq, n_docs]*/, float unscale_d,
     const unsigned char* __restrict__ img_q /* nullable: the queries' split images (maxsim_split_queries_kernel) */,
@@ -1514,12 +1514,13 @@ int ms_run(amdr_maxsim* h, const float* Q_dev, int nq, int q_len, int k, float* 
     float* nsum_q = unscale_q + nq;
     const char* rs = getenv("AMDR_MAXSIM_RESCORE");  // "0": one wave per pair (the round-3 form; A/B, tests)
     const bool by_doc = !(rs && rs[0] == '0');
-    // documents per block of pass 1 (round 4, scripts/sweep_maxsim_docs.sh, ms per hybrid step: UCC-en 8 / 16 / 32 / 64 /
-    // 128: 1.056 / 1.035 / 1.027 / 1.080 / 1.064; the Civil-Code-zh channel 1.28 / 1.21 / 1.18 / 1.17 / 1.18)
-    const char* fc = getenv("AMDR_MAXSIM_FINAL");  // "0": rank the whole re-scored rows (rowscores_topk_kernel; A/B, tests)
-    const bool final_cand = !(fc && fc[0] == '0');
+    // documents per block of pass 1 (round 4, scripts/ab_maxsim_env.py — variants interleaved in one process, channel ms):
+    // UCC-en 16 / 24 / 29 / 32: 0.891 / 0.884 / 0.897 / 0.903, Civil-Code-zh 16 / 24 / 32 / 48 / 64: 1.161 / 1.161 / 1.163 /
+    // 1.101* / 1.095* (*another box: 32 = 1.090).  Whole rounds of the chip's block slots (29 documents: 3 066 blocks = 3.99
+    // rounds of 768, against 3.6 at 32) bought nothing, nor did 2 or 4 ring stages (AMDR_MAXSIM_RING1; 5 or 2 blocks per
+    // CU instead of 3: -0.5 % / +2 %): the pass sits on a plateau that scheduling does not move.
     const char* dpb = getenv("AMDR_MAXSIM_DOCS");
-    long docs = dpb && atoi(dpb) > 0 ? atoi(dpb) : 32;
+    long docs = dpb && atoi(dpb) > 0 ? atoi(dpb) : 24;
     while (ceil_div(h->n_docs, docs) > 65535) docs *= 2;
     if (by_doc)
       hipLaunchKernelGGL(maxsim_split_queries_kernel, dim3(ceil_div(nq, 4)), dim3(256), 0, st, Q_dev, nq, q_len, img_q,
@@ -1534,11 +1535,20 @@ int ms_run(amdr_maxsim* h, const float* Q_dev, int nq, int q_len, int k, float* 
     } else {
       const char* ps = getenv("AMDR_MAXSIM_PRESPLIT");  // "0": every block of pass 1 splits its queries itself (A/B)
       const bool presplit = by_doc && !(ps && ps[0] == '0');
-      AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_hi2_ring_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   3 * 16384));
-      hipLaunchKernelGGL((maxsim_hi2_ring_kernel<3>), dim3(ceil_div(nq, 2 * kMsQ2), ceil_div(h->n_docs, docs)),
-                         dim3(kMsQ2 * 64), 3 * 16384, st, h->img_hi, h->doc_ptr, (long)h->n_docs, (int)docs, Q_dev, nq,
-                         q_len, approx, unscale_d, presplit ? img_q : (const unsigned char*)nullptr, unscale_q);
+      const char* r1 = getenv("AMDR_MAXSIM_RING1");  // LDS stages of pass 1 (2 / 3 / 4: 5 / 3 / 2 blocks per CU)
+      const int nb1 = r1 ? atoi(r1) : 3;
+#define AMDR_MS_PASS1(NB)                                                                                              \
+  do {                                                                                                                 \
+    AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_hi2_ring_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                 NB * 16384));                                                                         \
+    hipLaunchKernelGGL((maxsim_hi2_ring_kernel<NB>), dim3(ceil_div(nq, 2 * kMsQ2), ceil_div(h->n_docs, docs)),        \
+                       dim3(kMsQ2 * 64), NB * 16384, st, h->img_hi, h->doc_ptr, (long)h->n_docs, (int)docs, Q_dev, nq, \
+                       q_len, approx, unscale_d, presplit ? img_q : (const unsigned char*)nullptr, unscale_q);         \
+  } while (0)
+      if (nb1 == 2) AMDR_MS_PASS1(2);
+      else if (nb1 == 4) AMDR_MS_PASS1(4);
+      else AMDR_MS_PASS1(3);
+#undef AMDR_MS_PASS1
     }
     if (by_doc) AMDR_HIP(hipMemsetAsync(dcnt, 0, (size_t)h->n_docs * sizeof(int), st));
     hipLaunchKernelGGL(maxsim_select_kernel, dim3(nq), dim3(64), (size_t)cap_sel * sizeof(C32), st, approx,
