@@ -1514,6 +1514,8 @@ int ms_run(amdr_maxsim* h, const float* Q_dev, int nq, int q_len, int k, float* 
     float* nsum_q = unscale_q + nq;
     const char* rs = getenv("AMDR_MAXSIM_RESCORE");  // "0": one wave per pair (the round-3 form; A/B, tests)
     const bool by_doc = !(rs && rs[0] == '0');
+    const char* fc = getenv("AMDR_MAXSIM_FINAL");  // "0": rank the whole re-scored rows (rowscores_topk_kernel; A/B, tests)
+    const bool final_cand = !(fc && fc[0] == '0');
     // documents per block of pass 1 (round 4, scripts/ab_maxsim_env.py — variants interleaved in one process, channel ms):
     // UCC-en 16 / 24 / 29 / 32: 0.891 / 0.884 / 0.897 / 0.903, Civil-Code-zh 16 / 24 / 32 / 48 / 64: 1.161 / 1.161 / 1.163 /
     // 1.101* / 1.095* (*another box: 32 = 1.090).  Whole rounds of the chip's block slots (29 documents: 3 066 blocks = 3.99
