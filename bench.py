@@ -56,12 +56,12 @@ def kernel_sources_fingerprint(key):
     """sha256 (16 hex digits) over the kernel sources the object depends on: what scripts/pmc_traffic.py stamps on its
     traffic entry (same file lists: scripts/pmc_traffic.py SOURCES / SCAN_SOURCES)."""
     import hashlib
-    lists = {"ucc_hybrid": ("dense.hip", "dense_panel.hip", "common.hpp"),
-             "dense_only_d384": ("dense.hip", "dense_panel.hip", "common.hpp"),
+    lists = {"ucc_hybrid": ("dense.hip", "dense_dot.hpp", "dense_panel.hip", "common.hpp"),
+             "dense_only_d384": ("dense.hip", "dense_dot.hpp", "dense_panel.hip", "common.hpp"),
              "ucc_colbert": ("maxsim.hip", "topk.hpp", "common.hpp"),
              "full_hybrid_rerank": ("maxsim.hip", "topk.hpp", "common.hpp")}
     h = hashlib.sha256()
-    for name in lists.get(key, ("dense.hip", "dense_hi.hip", "dense_mfma.hip", "topk.hpp", "common.hpp")):
+    for name in lists.get(key, ("dense.hip", "dense_dot.hpp", "dense_hi.hip", "dense_mfma.hip", "topk.hpp", "common.hpp")):
         h.update(name.encode())
         h.update((ROOT / "legal-rag_amd" / "csrc" / name).read_bytes())
     return h.hexdigest()[:16]
@@ -821,6 +821,8 @@ def run_shard8_proxy(torch, device, n=1_250_000, d=768, k=10, steps=30):
             "stream_ms_per_search": per_search_ms, "tail_us_behind_the_scans": (per_search_ms - scan_per_search) * 1e3,
             "latency_ms_p50": lat[len(lat) // 2], "latency_ms_max": lat[-1], "queries_per_s": B / (per_search_ms * 1e-3),
             "scan_frac_of_hbm_peak": bytes_scan / (scan_per_search * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_search": bytes_scan,
+            "traffic": pmc_traffic(f"shard8_proxy_b{B}", "dense_hi_tilemax_kernel"),  # sample + scan + re-scoring, PMC
             "exchange_pack_plus_merge_us_world1": ex_us, "unresolved_by_the_rounding_bound": unresolved,
             "passes": passes, "passes_that_also_ran_the_exact_chain": flagged,
             "ids_and_score_bits_equal_exact_first_pass": same})

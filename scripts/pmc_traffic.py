@@ -28,12 +28,12 @@ sys.path.insert(0, str(ROOT))
 
 # kernel sources an object's traffic depends on: its entry is reported only while THESE files are unchanged
 SOURCES = {
-    "ucc_hybrid": ("dense.hip", "dense_panel.hip", "common.hpp"),
-    "dense_only_d384": ("dense.hip", "dense_panel.hip", "common.hpp"),
+    "ucc_hybrid": ("dense.hip", "dense_dot.hpp", "dense_panel.hip", "common.hpp"),
+    "dense_only_d384": ("dense.hip", "dense_dot.hpp", "dense_panel.hip", "common.hpp"),
     "ucc_colbert": ("maxsim.hip", "topk.hpp", "common.hpp"),
     "full_hybrid_rerank": ("maxsim.hip", "topk.hpp", "common.hpp"),
 }
-SCAN_SOURCES = ("dense.hip", "dense_hi.hip", "dense_mfma.hip", "topk.hpp", "common.hpp")
+SCAN_SOURCES = ("dense.hip", "dense_dot.hpp", "dense_hi.hip", "dense_mfma.hip", "topk.hpp", "common.hpp")
 
 
 def sources_fingerprint(key: str) -> str:
@@ -68,6 +68,9 @@ OBJECTS = {
     "shard8_proxy_b64": (["scripts/run_dense_once.py", "1250000", "64", "768", "5"],
                          ["dense_hi_tilemax_kernel<12, true>", "dense_hi_tilemax_kernel<12, false>",
                           "dense_rescore_tiles_kernel"], None),
+    "shard8_proxy_b256": (["scripts/run_dense_once.py", "1250000", "256", "768", "5"],
+                          ["dense_hi_tilemax_kernel<12, true>", "dense_hi_tilemax_kernel<12, false>",
+                           "dense_rescore_tiles_kernel"], None),
 }
 
 
