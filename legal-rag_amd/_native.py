@@ -277,7 +277,7 @@ class DenseIndex:
 
     def plan_info(self, nq: int, k: int) -> str:
         """Kernels a search of nq queries at depth k launches on this index, and the cut of the work."""
-        buf = C.create_string_buffer(512)
+        buf = C.create_string_buffer(1024)
         _check(load().amdr_dense_plan_info(self._h, C.c_int32(nq), C.c_int32(k), buf, C.c_int32(512)),
                "amdr_dense_plan_info")
         return buf.value.decode()
@@ -477,7 +477,7 @@ class MaxSimIndex:
 
     def plan_info(self, nq: int) -> str:
         """Kernels and arithmetic form a search of nq queries launches (no device work)."""
-        buf = C.create_string_buffer(512)
+        buf = C.create_string_buffer(1024)
         _check(load().amdr_maxsim_plan_info(self._h, C.c_int32(nq), buf, C.c_int32(512)), "amdr_maxsim_plan_info")
         return buf.value.decode()
 

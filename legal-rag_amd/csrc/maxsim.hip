@@ -1726,13 +1726,15 @@ int amdr_maxsim_plan_info(const amdr_maxsim_t* h, int32_t nq, char* buf, int32_t
   const bool batch = nq >= kMsQ;
   if (half && batch && h->img_hi && !(getenv("AMDR_MAXSIM_TWOPASS") && getenv("AMDR_MAXSIM_TWOPASS")[0] == '0'))
     snprintf(buf, buf_len,
-             "maxsim_hi2_ring_kernel split-fp16 two-pass top-k (k <= n_docs / 4): pass 1 hi parts only (1 x "
-             "v_mfma_f32_32x32x16_f16 per block, two queries per wave) + maxsim_select_kernel + %s "
-             "(hi + lo/2048, 3 MFMAs per block, candidates only) + rowscores_topk_kernel; full score rows: "
-             "maxsim_scores_ring_kernel",
+             "maxsim_hi2_ring_kernel split-fp16 two-pass top-k (k <= n_docs / 4): maxsim_split_queries_kernel + pass 1 hi "
+             "parts only (1 x v_mfma_f32_32x32x16_f16 per block, two queries per wave) + maxsim_select_kernel + %s "
+             "(hi + lo/2048, 3 MFMAs per block, candidates only) + %s; full score rows: maxsim_scores_ring_kernel",
              (getenv("AMDR_MAXSIM_RESCORE") && getenv("AMDR_MAXSIM_RESCORE")[0] == '0')
                  ? "maxsim_rescore_kernel (one wave per candidate pair)"
-                 : "maxsim_rescore_ring_kernel (pairs grouped by document: a block = one document x 8 of its queries)");
+                 : "maxsim_rescore_ring_kernel (pairs grouped by document: a block = one document x 8 of its queries)",
+             (getenv("AMDR_MAXSIM_FINAL") && getenv("AMDR_MAXSIM_FINAL")[0] == '0')
+                 ? "rowscores_topk_kernel"
+                 : "maxsim_final_topk_kernel (the candidates only)");
   else if (half)
     snprintf(buf, buf_len, "%s split-fp16 (hi + lo/2048, 3 x v_mfma_f32_32x32x16_f16 per block) + rowscores_topk_kernel",
              batch ? "maxsim_scores_ring_kernel" : "maxsim_scores_h_kernel");
