@@ -112,7 +112,9 @@ class BM25Retriever:
                 joined = "\0".join(qs)
                 if any(w in joined for w in text._ASCII_DICT_WORDS):  # rare: find the queries concerned
                     hard = hard | np.fromiter((any(w in q for w in text._ASCII_DICT_WORDS) for q in qs), dtype=bool, count=n)
-            exact = np.full(n, self.index_tokenizer != "char", dtype=bool)
+            # text without Han characters is tokenised exactly whatever the index was built with (tokenize_query's rule:
+            # only a Han query on a char-built index, or without jieba, is a stand-in result)
+            exact = np.ones(n, dtype=bool)
             if not hard.any():
                 return terms, q_ptr, exact
         else:

@@ -126,7 +126,10 @@ class CrossEncoderReranker:
 
     def score_pairs(self, pairs: Sequence[Tuple[str, str]]) -> List[float]:
         """(query, doc) pairs of SEVERAL queries through the model in full batches — the batched form behind
-        HybridRetriever.search_batch (one forward per `batch_size` pairs instead of one short batch per query)."""
+        HybridRetriever.search_batch (one forward per `batch_size` pairs instead of one short batch per query).  A
+        forward's padding length and batch composition differ from the per-query score_batch call's: with a real
+        cross-encoder the scores agree to floating-point noise of the model, not bit for bit (the stand-in scorer and
+        the blend kernel are exact, so search_batch(qs)[i] == search(qs[i]) holds exactly in the tests)."""
         torch, out = self._torch, []
         with torch.inference_mode():
             for lo in range(0, len(pairs), self.batch_size):

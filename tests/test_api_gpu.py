@@ -365,6 +365,30 @@ def test_search_native_stage_equals_per_channel_path(ucc_index, monkeypatch):
             assert got == exp, (q, top_k)
 
 
+def test_search_one_launch_step_equals_the_separate_launches(ucc_index, monkeypatch):
+    """search() without ColBERT issues ONE launch per query (amdr_hybrid_small_device: BM25 + dense + fusion of a
+    serving corpus); AMDR_HYBRID_SMALL=0 pins bm25.search_device + dense.search_fuse_device.  Identical hits, scores
+    and breakdowns through the API, and both equal to the per-channel path (AMDR_SEARCH_NATIVE=0)."""
+    from legal_rag_amd.retrieval.hybrid_retriever import HybridRetriever
+    cfg, _ = ucc_index
+    cfg2 = copy.deepcopy(cfg)
+    cfg2.retrieval.enable_colbert = False
+    cfg2.retrieval.enable_rerank = False
+    r = HybridRetriever(cfg2)
+    assert r._native_channels(10) is not None
+    for top_k in (1, 10, 16):
+        for q in QUESTIONS + ["", "the", "zzzz qqqq"]:
+            monkeypatch.setenv("AMDR_HYBRID_SMALL", "0")
+            exp = [dump(h) for h in r.search(q, top_k=top_k)]
+            monkeypatch.setenv("AMDR_HYBRID_SMALL", "1")
+            got = [dump(h) for h in r.search(q, top_k=top_k)]
+            monkeypatch.delenv("AMDR_HYBRID_SMALL")
+            monkeypatch.setenv("AMDR_SEARCH_NATIVE", "0")
+            per = [dump(h) for h in r.search(q, top_k=top_k)]
+            monkeypatch.delenv("AMDR_SEARCH_NATIVE")
+            assert got == exp == per, (q, top_k)
+
+
 def test_search_and_search_batch_from_two_threads(ucc_index):
     """Service threads in search() while another thread drives search_batch() on the same
     singletons (VectorStore / BM25 / MaxSim handles): every result equals the single-threaded one."""
