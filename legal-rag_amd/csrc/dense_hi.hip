@@ -38,6 +38,7 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 constexpr int kHiWaves = 8;
 constexpr int kHiKC = 64;              // floats of every row per chunk
 constexpr int kHiStageBytes = 32 * 128;  // 32 rows x 64 halves
+constexpr int kHiWbufMax = 384;          // entries of a wave's staging buffer at most (hi_wbuf_entries)
 
 // stage: row r (0..31) at byte r*128, its 16-B slot s (0..7) at s ^ ((r >> 1) & 7) (the image of dense_mfma.hip's stage)
 __device__ __forceinline__ int hi_stage_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
@@ -319,10 +320,11 @@ __device__ __forceinline__ void hi_tilemax_pass(const float* __restrict__ X, lon
     unsigned int* bb = reinterpret_cast<unsigned int*>(bh + 64);
     if (wave == 0) bh[lane] = 0;
     __syncthreads();
-    int pos[4];
-    unsigned int qq[4];
+    constexpr int kJ = kHiWbufMax / 64;
+    int pos[kJ];
+    unsigned int qq[kJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < kJ; ++j) {
       const int i = lane + 64 * j;
       pos[j] = 0, qq[j] = 0u;
       if (i < wcnt) {
@@ -337,7 +339,7 @@ __device__ __forceinline__ void hi_tilemax_pass(const float* __restrict__ X, lon
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < kJ; ++j) {
       const int i = lane + 64 * j;
       if (i < wcnt) {
         C32 c = wbuf[i];
@@ -533,10 +535,19 @@ __global__ __launch_bounds__(64) void dense_hi_check_kernel(const float* __restr
 bool dense_hi_supported(int d) { return d >= 128 && d <= 1024 && d % 128 == 0; }
 int dense_hi_max_queries(int d) { return hi_query_tile(d); }
 
-static int hi_wbuf_entries(int d) {  // 16 / 8 KiB of LDS for the 8 waves
+// Entries of a wave's staging buffer: what the 160 KiB of LDS leave beside the query tile and the stages, at most 384
+// (24 KiB for the 8 waves).  A buffer that fills in the middle of a wave's run is flushed entry by entry with returning
+// atomics on the per-query counters — 2 048 waves x ~90 entries on 48 addresses at 7.5 M x 1 024 rows, where the buffer
+// held 128: the scan took 5.09 ms against 4.71 with the flat list of round 3.  Sized so that a run's entries fit (the
+// expected number is kc x sample stride x queries x tiles per wave / tiles = ~90-160), only the block-binned flush at the
+// end of the run is left: one atomic per (block, query).
+static int hi_wbuf_entries(int d) {
   const char* e = getenv("AMDR_DENSE_HI_WBUF");  // test hook: a 64-entry buffer flushes after every emitting tile
   if (e && atoi(e) >= 64 && atoi(e) <= 128) return atoi(e);
-  return d <= 768 ? 256 : 128;
+  const long room = 160 * 1024 - 1024 - (long)hi_query_tile(d) * d * 2 - (long)kHiWaves * kHiStageBytes;
+  long n = room / ((long)kHiWaves * (long)sizeof(C32)) / 64 * 64;
+  n = n > kHiWbufMax ? kHiWbufMax : n;
+  return (int)(n < 128 ? 128 : n);
 }
 static size_t dense_hi_lds(int d, bool emit) {
   return (size_t)hi_query_tile(d) * d * 2 + kHiWaves * kHiStageBytes +
