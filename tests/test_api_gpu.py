@@ -389,6 +389,31 @@ def test_search_one_launch_step_equals_the_separate_launches(ucc_index, monkeypa
             assert got == exp == per, (q, top_k)
 
 
+def test_failing_colbert_encoder_degrades_locally_but_raises_on_a_sharded_index(ucc_index, monkeypatch):
+    """A ColBERT query encoder that raises empties the channel (the reference swallows ColBERT errors,
+    hybrid_retriever.py:244-245) — except on a row-sharded index, where dropping a channel would be a rank-local decision
+    inside an SPMD exchange (the other ranks all-gather three packed channels): there the error propagates."""
+    import types
+    from legal_rag_amd.retrieval.hybrid_retriever import HybridRetriever
+    cfg, _ = ucc_index
+    cfg2 = copy.deepcopy(cfg)
+    cfg2.retrieval.enable_rerank = False
+    r = HybridRetriever(cfg2)
+    store, _bm, col = r._native_channels(10)
+    assert col is not None
+
+    def boom(*a, **k):
+        raise RuntimeError("encoder down")
+    for name in ("encode_queries_tensor", "encode_queries", "encode_query"):
+        if hasattr(col._encoder, name):
+            monkeypatch.setattr(col._encoder, name, boom)
+    hits = r.search(QUESTIONS[0], top_k=5)
+    assert hits and all("colbert" not in (h.score_breakdown or {}).get("channel", []) for h in hits)
+    monkeypatch.setattr(store.index, "spec", types.SimpleNamespace(group=None), raising=False)
+    with pytest.raises(RuntimeError, match="encoder down"):
+        r.search(QUESTIONS[0], top_k=5)
+
+
 def test_search_and_search_batch_from_two_threads(ucc_index):
     """Service threads in search() while another thread drives search_batch() on the same
     singletons (VectorStore / BM25 / MaxSim handles): every result equals the single-threaded one."""
