@@ -50,14 +50,15 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA == fp32 vector peak
+F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16 / bf16 matrix peak
 
 
 def kernel_sources_fingerprint(key):
     """sha256 (16 hex digits) over the kernel sources the object depends on: what scripts/pmc_traffic.py stamps on its
     traffic entry (same file lists: scripts/pmc_traffic.py SOURCES / SCAN_SOURCES)."""
     import hashlib
-    lists = {"ucc_hybrid": ("dense.hip", "dense_dot.hpp", "dense_panel.hip", "common.hpp"),
-             "dense_only_d384": ("dense.hip", "dense_dot.hpp", "dense_panel.hip", "common.hpp"),
+    lists = {"ucc_hybrid": ("dense.hip", "dense_dot.hpp", "dense_panel.hip", "dense_small_hi.hip", "common.hpp"),
+             "dense_only_d384": ("dense.hip", "dense_dot.hpp", "dense_panel.hip", "dense_small_hi.hip", "common.hpp"),
              "ucc_colbert": ("maxsim.hip", "topk.hpp", "common.hpp"),
              "full_hybrid_rerank": ("maxsim.hip", "topk.hpp", "common.hpp")}
     h = hashlib.sha256()
@@ -65,6 +66,19 @@ def kernel_sources_fingerprint(key):
         h.update(name.encode())
         h.update((ROOT / "legal-rag_amd" / "csrc" / name).read_bytes())
     return h.hexdigest()[:16]
+
+
+def dense_scores_roofline(plan, flops, kern_ms):
+    """(kernel label, peak TFLOP/s, bound note) of the long-batch dense scores launch the plan names: the exact fp32 form
+    (dense_panel_scores_kernel, fp32 matrix instructions) or the first pass of the two-pass form (dsh_split_queries_kernel +
+    dsh_scores_kernel: fp16 matrix instructions on fp16 roundings, 16 x the rate; exact re-scoring follows in the select
+    kernel).  `achieved` is the ALGORITHMIC 2 n d nq over the bracketed launches either way."""
+    name = plan.split(" ")[0]
+    if name.startswith("dsh_scores_kernel"):
+        return ("dsh_split_queries_kernel + dsh_scores_kernel (first pass of the two-pass form: v_mfma_f32_32x32x16_f16 on fp16 "
+                "roundings of both operands; every candidate inside the proven margin is re-scored in exact fp32 by "
+                "dense_hi_select_fuse_kernel)", F16_MFMA_PEAK_TFLOPS)
+    return (name + " (v_mfma_f32_16x16x4_f32, exact fp32)", F32_MFMA_PEAK_TFLOPS)
 
 
 def pmc_traffic(key, kernel_prefix, plan=None):
@@ -331,7 +345,6 @@ def event_ms(torch, fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
-F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16 / bf16 matrix peak
 
 
 def maxsim_roofline(ms, tokens, nq, q_len=32, dim=128, note="", plan=""):
@@ -423,9 +436,9 @@ def run_dense_only_d384(torch, local, K, steps, rep):
         out[name] = {"queries_per_step": nq, "value": nq / (st["median"] * 1e-3), "unit": "queries/s", "timing": st,
                      "recall_at_10": rec, "id_agreement_vs_oracle": float(np.mean(got_i == ei)),
                      "max_abs_score_err_vs_oracle": float(np.max(np.abs(got_s - es))),
-                     "roofline": {"bound": "mfma", "kernel": plan.split(" ")[0] + " (v_mfma_f32_16x16x4_f32, exact fp32)",
-                                  "plan": plan, "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": ach / F32_MFMA_PEAK_TFLOPS,
+                     "roofline": {"bound": "mfma", "kernel": dense_scores_roofline(plan, flops, kern_ms)[0],
+                                  "plan": plan, "achieved": ach, "peak": dense_scores_roofline(plan, flops, kern_ms)[1],
+                                  "unit": "TFLOP/s", "frac": ach / dense_scores_roofline(plan, flops, kern_ms)[1],
                                   "traffic": pmc_traffic("dense_only_d384", plan.split(" ")[0], plan) if nq > 20000 else None,
                                   "launch_ms": kern_ms,
                                   "algorithmic_flops": flops,
@@ -1049,9 +1062,10 @@ def main():
         flops_per_launch = 2.0 * rows_local * d * nq
         per_launch_ms = scan_ms / max(launches, 1)
         achieved = flops_per_launch / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
-        roofline = {"bound": "mfma", "kernel": f"{kernel} (v_mfma_f32_16x16x4_f32, exact fp32)", "plan": plan,
-                    "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / F32_MFMA_PEAK_TFLOPS,
+        klabel, kpeak = dense_scores_roofline(plan, flops_per_launch, per_launch_ms)
+        roofline = {"bound": "mfma", "kernel": klabel, "plan": plan,
+                    "achieved": achieved, "peak": kpeak, "unit": "TFLOP/s",
+                    "frac": achieved / kpeak,
                     "traffic": pmc_traffic("ucc_hybrid", kernel, plan) if (rep == 32 and shard == "queries") else None,
                     "launch_ms": per_launch_ms, "launches_timed": launches, "launch_ms_windows": launch_ms_windows,
                     "algorithmic_flops": flops_per_launch,
@@ -1063,7 +1077,7 @@ def main():
             "metric": "queries/sec + Recall@10 (hybrid top-10) on UCC-en", "value": value, "unit": "queries/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": st["median"],
             "higher_is_better": True, "scaling": "weak" if shard == "queries" else "strong", "vs_baseline": None,
-            "dtype": "f32 dense / f64 bm25+fusion", "data": "UCC-en law text (fixture) with deterministic stand-in "
+            "dtype": "f32 dense (long batches: fp16 first pass, candidates re-scored in f32) / f64 bm25+fusion", "data": "UCC-en law text (fixture) with deterministic stand-in "
             "embeddings (no BGE weights offline) and a seeded synthetic query set",
             "config": {"workload": "UCC-en 591 chunks, dense(768-d FlatIP)+BM25 hybrid fusion top-10 "
                                    "(BASELINE configs[1])", "queries_per_step_per_gpu": nq, "unique_queries": nq0,
@@ -1125,6 +1139,37 @@ def main():
                     "fused_ids_equal_the_resident_step": same_ids, "blob_bytes": len(blob)}
             except Exception as e:  # noqa: BLE001 - report, never hide
                 result["with_tokenisation"] = {"error": repr(e)}
+        if rank == 0 and shard == "queries" and plan.startswith("dsh_scores_kernel"):
+            # the same step with the dense channel's EXACT long-batch form (AMDR_DENSE_SMALL_HI=0: dense_panel_scores_kernel on
+            # the fp32 matrix instructions + dense_select_fuse_kernel) — what `value` was measured on in rounds 1-3
+            prev = os.environ.get("AMDR_DENSE_SMALL_HI")
+            os.environ["AMDR_DENSE_SMALL_HI"] = "0"
+            try:
+                for _ in range(20):
+                    step()
+                pw = []
+                dts_e = timed_windows(torch, dist, 1, device, step, a.steps, 0, 3, before=lambda wi: R.dense.profile_begin(a.steps),
+                                      after=lambda wi: pw.append(R.dense.profile_end()))
+                st_e = window_stats(dts_e, a.steps)
+                wi_e = min(range(len(dts_e)), key=lambda i: abs(dts_e[i] / a.steps * 1e3 - st_e["median"]))
+                ms_e = pw[wi_e][0] / max(pw[wi_e][1], 1)
+                plan_e = R.dense.plan_info(nq, K)
+                ids_e, cnt_e = last["res"].ids[:, :K].cpu().numpy(), last["res"].count.cpu().numpy()
+                within = np.arange(K)[None, :] < np.minimum(cnt, K)[:, None]  # (entries past count[q] are unspecified)
+                same = bool(np.array_equal(cnt_e, cnt) and np.array_equal(ids_e[within], ids[within]))
+                result["exact_form"] = {
+                    "note": "AMDR_DENSE_SMALL_HI=0: the dense channel's exact fp32 long-batch form, same step, same run",
+                    "value": nq / (st_e["median"] * 1e-3), "ms_per_step": st_e["median"], "timing": st_e, "plan": plan_e,
+                    "fused_ids_and_counts_equal_the_two_pass_form": same,
+                    "roofline": {"bound": "mfma", "kernel": dense_scores_roofline(plan_e, flops_per_launch, ms_e)[0],
+                                 "achieved": flops_per_launch / (ms_e * 1e-3) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS,
+                                 "unit": "TFLOP/s", "frac": flops_per_launch / (ms_e * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                                 "launch_ms": ms_e}}
+            finally:
+                if prev is None:
+                    os.environ.pop("AMDR_DENSE_SMALL_HI", None)
+                else:
+                    os.environ["AMDR_DENSE_SMALL_HI"] = prev
         R.close()
         del R
         torch.cuda.empty_cache()

@@ -44,6 +44,7 @@ extern "C" {
 #define AMDR_MAXSIM_QLEN 32 /* ColBERT query length after [MASK] padding */
 
 typedef struct amdr_dense amdr_dense_t;
+typedef struct amdr_dense_small amdr_dense_small_t;
 typedef struct amdr_bm25 amdr_bm25_t;
 typedef struct amdr_maxsim amdr_maxsim_t;
 typedef struct amdr_tokenizer amdr_tokenizer_t;
@@ -263,6 +264,19 @@ int amdr_hybrid_small_device(amdr_dense_t* dense, amdr_bm25_t* bm25, const float
                              const int64_t* dense_row2uid, const int64_t* bm25_row2uid, float* dense_scores_dev,
                              int64_t* dense_ids_dev, double* bm25_scores_dev, int64_t* bm25_ids_dev, int64_t* out_ids,
                              double* out_vals, int32_t* out_mask, int32_t* out_count, void* stream);
+
+/* EXPERIMENTAL (round 4; not on the product's search path yet): the first half of a two-pass form of the long-batch dense
+ * channel on a short corpus (search_dense over a batch, hybrid_retriever.py:181-189).  approx_device writes, for every
+ * query and chunk row, the dot product of the fp16 roundings of the scaled operands — S[nq, ldS] (ldS >= the rows padded to
+ * 32, a multiple of 4; columns [n, padded) are 0) — on the fp16 matrix instructions, and per query the PROVEN bound
+ * eps[q] >= |S[q][r] - <Q[q], X[r]>| for every row r (NaN: a non-finite query or one outside the scale range — no bound),
+ * in the units of the exact score.  A second pass that re-scores the rows with S >= (k-th best of S) - 2 eps exactly returns
+ * the exact top-k.  create takes the statistics and the fp16 image of the dense handle's matrix as it is NOW (rows added
+ * later are not seen); d must be a multiple of 128 in [128, 1024]; the dense handle must outlive this one. */
+int amdr_dense_small_create(amdr_dense_t* dense, amdr_dense_small_t** out);
+int amdr_dense_small_approx_device(amdr_dense_small_t* h, const float* Q_dev, int32_t nq, float* S_dev, int64_t ldS,
+                                   float* eps_dev /* nullable [nq] */, void* stream);
+int amdr_dense_small_destroy(amdr_dense_small_t* h);
 
 /* Rerank blend over the first min(top_n, count[q]) fused hits of each query:
  * norm = minmax(ce_raw); score = (1-beta)*score + beta*norm; the candidates

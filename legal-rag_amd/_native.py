@@ -29,7 +29,7 @@ FV = dict(score=0, rrf_norm=1, weighted_sum=2, dense_norm=3, bm25_norm=4, colber
 EXPORTS = (
     "amdr_last_error", "amdr_version", "amdr_device_count", "amdr_device_name",
     "amdr_dense_create", "amdr_dense_create_from_device", "amdr_dense_add", "amdr_dense_ntotal", "amdr_dense_dim",
-    "amdr_dense_reserve", "amdr_dense_search", "amdr_dense_search_device", "amdr_dense_search_fuse_device", "amdr_hybrid_small_device", "amdr_dense_read_rows", "amdr_dense_score_rows",
+    "amdr_dense_reserve", "amdr_dense_search", "amdr_dense_search_device", "amdr_dense_search_fuse_device", "amdr_hybrid_small_device", "amdr_dense_small_create", "amdr_dense_small_approx_device", "amdr_dense_small_destroy", "amdr_dense_read_rows", "amdr_dense_score_rows",
     "amdr_dense_plan_info", "amdr_dense_workspace_plan", "amdr_dense_hi_counters", "amdr_dense_profile_begin", "amdr_dense_profile_end", "amdr_dense_destroy",
     "amdr_bm25_create", "amdr_bm25_ndocs", "amdr_bm25_reserve", "amdr_bm25_search", "amdr_bm25_search_device",
     "amdr_bm25_scores", "amdr_bm25_destroy",
@@ -50,7 +50,7 @@ SIGNATURES = {
     "amdr_last_error": "", "amdr_version": "", "amdr_device_count": "P", "amdr_device_name": "iPi",
     "amdr_dense_create": "PliiP", "amdr_dense_create_from_device": "PliiP", "amdr_dense_add": "PPl",
     "amdr_dense_ntotal": "PP", "amdr_dense_dim": "PP", "amdr_dense_reserve": "Pii", "amdr_dense_search": "PPiiPP",
-    "amdr_dense_search_device": "PPiiPPP", "amdr_dense_search_fuse_device": "PPiiPPPPiPPPPPPPP", "amdr_hybrid_small_device": "PPPPPiiiPPPPPPPPPPPP", "amdr_dense_read_rows": "PllP", "amdr_dense_score_rows": "PPiPiP",
+    "amdr_dense_search_device": "PPiiPPP", "amdr_dense_search_fuse_device": "PPiiPPPPiPPPPPPPP", "amdr_hybrid_small_device": "PPPPPiiiPPPPPPPPPPPP", "amdr_dense_small_create": "PP", "amdr_dense_small_approx_device": "PPiPlPP", "amdr_dense_small_destroy": "P", "amdr_dense_read_rows": "PllP", "amdr_dense_score_rows": "PPiPiP",
     "amdr_dense_plan_info": "PiiPi", "amdr_dense_workspace_plan": "liiiP", "amdr_dense_hi_counters": "PP", "amdr_dense_profile_begin": "Pi", "amdr_dense_profile_end": "PPP", "amdr_dense_destroy": "P",
     "amdr_bm25_create": "PPPPPlldddiP", "amdr_bm25_ndocs": "PP", "amdr_bm25_reserve": "Piil",
     "amdr_bm25_search": "PPPiiPP", "amdr_bm25_search_device": "PPPiiPPP", "amdr_bm25_scores": "PPPiP",
@@ -602,6 +602,31 @@ def rerank_blend_device(nq: int, max_out: int, count: int, ids: int, vals: int, 
                                            _vp(mask), _vp(ce_raw), C.c_int32(top_n), C.c_double(beta),
                                            _vp(out_rerank), C.c_int32(device), _vp(stream)),
            "amdr_rerank_blend_device")
+
+
+class DenseSmallApprox:
+    """EXPERIMENTAL: fp16 first pass over a short corpus (amdr_dense_small_*): approximate scores of every (query, row)
+    with a proven per-query bound on their distance from the exact dot product.  Not on the search path."""
+
+    def __init__(self, dense: "DenseIndex"):
+        self._h = C.c_void_p()
+        self._dense = dense  # must outlive this handle
+        _check(load().amdr_dense_small_create(dense._h, C.byref(self._h)), "amdr_dense_small_create")
+
+    def approx_device(self, q_ptr: int, nq: int, s_ptr: int, ld: int, eps_ptr: int = 0, stream: int = 0) -> None:
+        _check(load().amdr_dense_small_approx_device(self._h, _vp(q_ptr), C.c_int32(nq), _vp(s_ptr), C.c_int64(ld), _vp(eps_ptr),
+                                                     _vp(stream)), "amdr_dense_small_approx_device")
+
+    def close(self) -> None:
+        if self._h:
+            load().amdr_dense_small_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 def hybrid_small_plan(dense: "DenseIndex", bm25: "BM25Index", nq: int, kd: int, kb: int, dense_row2uid: int,

@@ -152,6 +152,15 @@ struct FuseTail {  // the fusion that follows the dense channel: parameters, the
   int32_t* out_mask;
   int32_t* out_count;
 };
+// first pass of the two-pass long-batch form (dense_small_hi.hip): the fp16 image and statistics of a short chunk matrix
+int dense_small_create_from(int device, const float* X, int64_t n, int d, amdr_dense_small_t** out);
+int dense_small_reserve(amdr_dense_small_t* h, int nq_max);
+bool dense_small_usable(const amdr_dense_small_t* h);
+// second pass of the two-pass long-batch form (fuse.hip dense_hi_select_fuse_kernel): candidates inside the proven margin
+// of the approximate scores in S, exact dots, top-k (+ the fusion when t != nullptr)
+int dense_hi_select_launch(const FuseTail* t, int q0, const float* S, long ldS, long n, int m, int kd, const float* X,
+                           const float* Q, int d, const float* eps, float* fin_scores, int64_t* fin_ids,
+                           unsigned int* fallbacks, hipStream_t st);
 // one kernel ranks the rows of S and fuses (dense_select_fuse_kernel): single slab, <= 1 024 rows, kd + kb <= 32
 bool dense_select_fuse_applies(long n, int slabs, int m, int kd, int kb);
 // queries [q0, q0 + m) of the batch: S holds their score rows; writes their dense lists and their fused outputs

@@ -287,6 +287,12 @@ struct amdr_dense {
   hipEvent_t hi_ev = nullptr;       // recorded behind that copy: hi_adapt reads hi_host only once it has completed
   bool hi_copy_pending = false;
   unsigned int hi_seen[3] = {0u, 0u, 0u};  // the last completed copy
+  // two-pass long-batch form on a short corpus (dense_small_hi.hip + fuse.hip dense_hi_select_fuse_kernel): the fp16 image
+  // of X, made on first use (not while a stream is capturing) and dropped by add(); the per-query bounds; how many queries
+  // re-scored their whole row inside the second pass
+  amdr_dense_small_t* small = nullptr;
+  bool small_failed = false;
+  DevBuf small_eps, small_fb;
   // optional HIP-event ring bracketing the scan kernel alone (bench.py roofline)
   std::vector<hipEvent_t> prof_ev;
   int prof_used = 0;
@@ -393,6 +399,41 @@ size_t batched_part_need(const amdr_dense* h, int nq, int k) {
 
 // Two-pass form: scores S[q][row] (fp32-MFMA tiles for batches, one wave per (query, row) for the
 // 1-4 query call on a short corpus), then slab top-k (+ merge when there are several slabs).
+// The two-pass form of a LONG batch on a SHORT corpus: approximate scores on the fp16 matrix instructions (16 x the exact
+// form's rate), then per query the rows inside a proven margin of its k-th best re-scored exactly.  From
+// 4 096 queries per launch (below, the first pass's fixed cost eats the gain: 1 168 queries 28 us against 26 for the whole
+// exact search), one slab of <= 1 024 rows, d a multiple of 128, k (+ the BM25 depth when fused) <= 32.
+// AMDR_DENSE_SMALL_HI=0 pins the exact form, AMDR_DENSE_SMALL_HI_MIN the batch size it starts at.
+bool small_hi_shape(const amdr_dense* h, int m, int k, int kb) {
+  const char* e = getenv("AMDR_DENSE_SMALL_HI");
+  if (e && e[0] == '0') return false;
+  const char* mn = getenv("AMDR_DENSE_SMALL_HI_MIN");
+  const int m_min = mn && atoi(mn) > 0 ? atoi(mn) : 4096;
+  return m >= m_min && h->n >= 1 && h->n <= 1024 && h->d >= 128 && h->d <= 1024 && h->d % 128 == 0 && k >= 1 && k + kb <= 32;
+}
+// the image and the workspaces of that form; false: not available now (creation failed before, non-finite matrix, or a
+// stream is capturing and nothing was reserved) — the caller takes the exact form
+bool small_hi_ready(amdr_dense* h, int m, hipStream_t st) {
+  if (h->small_failed) return false;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  const bool capturing = st && hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+  if (!h->small) {
+    if (capturing) return false;
+    if (dense_small_create_from(h->device, h->X, h->n, h->d, &h->small) != AMDR_OK || !dense_small_usable(h->small)) {
+      h->small_failed = true;  // (a matrix the fp16 scale range cannot hold stays on the exact form)
+      return false;
+    }
+  }
+  const size_t need = (size_t)m * sizeof(float);
+  if (capturing && (h->small_eps.cap < need || !h->small_fb.p)) return false;
+  if (h->small_eps.ensure(need) != AMDR_OK) return false;
+  if (!h->small_fb.p) {
+    if (h->small_fb.ensure(sizeof(unsigned int)) != AMDR_OK) return false;
+    (void)hipMemset(h->small_fb.p, 0, sizeof(unsigned int));
+  }
+  return capturing ? true : dense_small_reserve(h->small, m) == AMDR_OK;
+}
+
 int run_search_batched(amdr_dense* h, int ws, const float* Q_dev, int nq, int k, float* scores_dev, int64_t* ids_dev,
                        hipStream_t st, bool row_waves = false, const FuseTail* tail = nullptr) {
   DevBuf& smat = h->smat[ws];
@@ -408,6 +449,22 @@ int run_search_batched(amdr_dense* h, int ws, const float* Q_dev, int nq, int k,
     if (m != chunk) dense_mfma_plan((long)h->n, h->d, m, k, &p);
     const bool prof = h->prof_on && (size_t)(h->prof_used + 2) <= h->prof_ev.size();
     if (prof) AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
+    const int kb_fused = tail ? tail->kb : 0;
+    const bool fuse_here = tail && dense_select_fuse_applies((long)h->n, p.slabs, m, k, tail->kb);
+    if (!row_waves && p.slabs == 1 && (fuse_here || !tail) && small_hi_shape(h, m, k, kb_fused) && small_hi_ready(h, m, st)) {
+      rc = amdr_dense_small_approx_device(h->small, Q_dev + (size_t)q0 * h->d, m, smat.as<float>(), p.ld,
+                                          h->small_eps.as<float>(), st);
+      if (rc) return rc;
+      if (prof) {
+        AMDR_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
+        h->prof_used += 2;
+      }
+      if ((rc = dense_hi_select_launch(tail, q0, smat.as<float>(), p.ld, (long)h->n, m, k, h->X, Q_dev + (size_t)q0 * h->d, h->d,
+                                       h->small_eps.as<float>(), scores_dev + (size_t)q0 * k, ids_dev + (size_t)q0 * k,
+                                       h->small_fb.as<unsigned int>(), st)))
+        return rc;
+      continue;
+    }
     if (row_waves) {
       hipLaunchKernelGGL(dense_all_scores_kernel, dim3(ceil_div((long)m * h->n, kWaves)), dim3(256), 0, st, h->X,
                          (long)h->n, h->d, Q_dev + (size_t)q0 * h->d, m, p.ld, smat.as<float>());
@@ -1083,6 +1140,12 @@ int amdr_dense_add(amdr_dense_t* h, const float* X_host, int64_t n_add) {
   AMDR_HIP(hipMemcpy(h->X + (size_t)h->n * h->d, X_host, (size_t)n_add * h->d * sizeof(float), hipMemcpyHostToDevice));
   const int64_t row0 = h->n;
   h->n += n_add;
+  if (h->small) {  // the short-corpus fp16 image is of the old matrix (and may point at freed memory): made again on demand
+    (void)hipDeviceSynchronize();
+    (void)amdr_dense_small_destroy(h->small);
+    h->small = nullptr;
+  }
+  h->small_failed = false;
   // the matrix changed: what the fp16 first pass learnt about it (width level, given up) starts over
   h->hi_level = 0;
   h->hi_off = false;
@@ -1140,6 +1203,8 @@ int amdr_dense_reserve(amdr_dense_t* h, int32_t nq_max, int32_t k_max) {
   }
   if ((rc = h->qbuf.ensure((size_t)nq_max * h->d * sizeof(float)))) return rc;
   if ((rc = h->sbuf.ensure((size_t)nq_max * k_max * sizeof(float)))) return rc;
+  if (small_hi_shape(h, nq_max, k_max < 16 ? k_max : 16, 0))  // (so that a later capture finds the two-pass form's buffers)
+    (void)small_hi_ready(h, batched_chunk(h, nq_max) < nq_max ? batched_chunk(h, nq_max) : nq_max, nullptr);
   return h->ibuf.ensure((size_t)nq_max * k_max * sizeof(int64_t));
 }
 
@@ -1340,6 +1405,14 @@ int amdr_dense_plan_info(const amdr_dense_t* h, int32_t nq, int32_t k, char* buf
     const int m = batched_chunk(h, nq);
     DenseMfmaPlan p;
     dense_mfma_plan((long)h->n, h->d, m, k, &p);
+    if (batched && p.slabs == 1 && small_hi_shape(h, m < nq ? m : nq, k, 0) && !h->small_failed) {
+      snprintf(buf, buf_len,
+               "dsh_scores_kernel fp16 first pass queries_per_launch=%d (dsh_split_queries_kernel + v_mfma_f32_32x32x16_f16 on "
+               "fp16 roundings of both operands, proven per-query bound) + dense_hi_select_fuse_kernel (rows inside 2 eps of the "
+               "k-th best re-scored exactly, top-k, fusion); exact form: dense_panel_scores_kernel",
+               m < nq ? m : nq);
+      return AMDR_OK;
+    }
     const char* tail = p.slabs == 1 ? "scores_slab_topk_kernel" : "scores_slab_topk_kernel + dense_merge_kernel";
     if (!batched) {
       snprintf(buf, buf_len, "dense_all_scores_kernel (one wave per query x row) + %s", tail);
@@ -1430,6 +1503,9 @@ int amdr_dense_destroy(amdr_dense_t* h) {
   h->sbuf.release();
   h->ibuf.release();
   h->stats.release();
+  if (h->small) (void)amdr_dense_small_destroy(h->small);
+  h->small_eps.release();
+  h->small_fb.release();
   if (h->hi_host) (void)hipHostFree(h->hi_host);
   if (h->hi_ev) (void)hipEventDestroy(h->hi_ev);
   delete h;

@@ -545,6 +545,256 @@ __global__ __launch_bounds__(64) void dense_select_fuse_kernel(amdr_fuse_params_
   fuse_packed_body<32, true>(P, c0, c1, none, nq, max_out, out_ids, out_vals, out_mask, out_count, pre, blockIdx.x * 2);
 }
 
+// ---- second pass of the two-pass long-batch dense form (round 4; first pass: dense_small_hi.hip) -----------------------
+// S holds APPROXIMATE scores (fp16 roundings of both operands, exact products, fp32 sums) and eps[q] the proven bound on
+// their distance from the exact dot products.  Per query (two per wave, a half-wave each, as dense_select_fuse_kernel):
+//   1. the rows whose approximate score reaches (k-th best lane maximum) - 2 eps — a superset of the rows within 2 eps of
+//      the k-th best approximate score, hence of every row that can be in the exact top-k — by the pair selector's own
+//      machinery with the threshold lowered by the margin; sorted by approximate score, cut back to the rows at or above
+//      (k-th best approximate score) - 2 eps;
+//   2. their EXACT fp32 dot products, one candidate at a time, the half-wave's 32 lanes across the row (512-byte loads, a
+//      butterfly sum);
+//   3. sorted by (exact score, lower id first): the dense channel's top-k — then the fusion, as before.
+// More than 32 rows inside the margin (mass near-ties), or no bound for the query (eps NaN): the half-wave re-scores EVERY
+// row exactly (into LDS) and the plain selectors run on that.  margin_scale (test hook) widens the margin.
+template <int V>
+__device__ __forceinline__ int select_row_pair_margin(const float* __restrict__ S, long ldS, long n, int q, bool has_q, int k,
+                                                      float margin, int lane, C32* scratch, C32& out, int& need) {
+  const float* row = S + (size_t)q * ldS;
+  const int j = lane & 31;
+  tk_v4f blk[V / 4];
+#pragma unroll
+  for (int u = 0; u < V / 4; ++u) {
+    const long c0 = 128L * u + 4 * j;
+    const tk_v4f z = {0.f, 0.f, 0.f, 0.f};
+    blk[u] = (has_q && c0 < ldS) ? *reinterpret_cast<const tk_v4f*>(row + c0) : z;
+  }
+  u32 sk[V];
+#pragma unroll
+  for (int u = 0; u < V / 4; ++u)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long r = 128L * u + 4 * j + e;
+      sk[4 * u + e] = (has_q && r < n) ? ord32(blk[u][e]) : 0u;
+    }
+  K32 lb;
+  lb.c = 0u;
+#pragma unroll
+  for (int v = 0; v < V; ++v) lb.c = sk[v] > lb.c ? sk[v] : lb.c;
+  const K32 sorted_best = wave_sortN_desc<K32, 32>(lb, lane);
+  const int src = (lane & 32) + (k - 1 < 31 ? k - 1 : 31);
+  const u32 T = (u32)__shfl((int)sorted_best.c, src);  // k-th lane best of this half: <= the k-th best score
+  u32 Te = 1u;                                          // (T == 0: fewer than k rows — every row is a candidate)
+  if (T > 1u) {
+    const float tf = unord32(T) - margin;  // (a NaN margin never gets here: the caller takes the exact path)
+    Te = ord32(tf);
+    Te = Te > 1u ? Te : 1u;
+  }
+  int mine = 0;
+#pragma unroll
+  for (int v = 0; v < V; ++v) mine += (sk[v] >= Te) ? 1 : 0;
+  int incl = mine;
+#pragma unroll
+  for (int sft = 1; sft < 32; sft <<= 1) {
+    const int o = __shfl_up(incl, sft, 32);
+    incl += (j >= sft) ? o : 0;
+  }
+  const int cnt = __shfl(incl, (lane & 32) + 31);
+  if (cnt > 32) return -1;  // (this lane's half; the caller votes)
+  int at = (lane & 32) + incl - mine;
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    if (sk[v] >= Te) {
+      C32 c;
+      c.c = ((u64)sk[v] << 32) | (u64)(0xffffffffu - (u32)(128 * (v >> 2) + 4 * j + (v & 3)));
+      scratch[at++] = c;
+    }
+  }
+  wave_lds_fence();
+  C32 c = (j < cnt) ? scratch[lane] : C32::pad();
+  c = wave_sortN_desc<C32, 32>(c, lane);
+  wave_lds_fence();
+  out = c;
+  // the rows at or above (k-th best approximate score) - margin: a prefix of the sorted survivors
+  const int kk = (k - 1 < 31 ? k - 1 : 31);
+  const float tk_f = __shfl(c.score(), (lane & 32) + kk);
+  const bool in = j < cnt && (cnt <= kk || c.score() >= tk_f - margin);
+  const unsigned long long m = __ballot(in);
+  need = __popcll((lane & 32) ? (m >> 32) : (m & 0xffffffffull));
+  return cnt;
+}
+
+template <bool FUSE>
+__global__ __launch_bounds__(64) void dense_hi_select_fuse_kernel(amdr_fuse_params_t P, const float* __restrict__ S, long ldS, long n,
+                                                                  int nq, int kd, const float* __restrict__ X,
+                                                                  const float* __restrict__ Q, int d,
+                                                                  const float* __restrict__ eps, float margin_scale,
+                                                                  float* __restrict__ fin_scores, long long* __restrict__ fin_ids,
+                                                                  ChanIn c0, ChanIn c1, int max_out,
+                                                                  long long* __restrict__ out_ids, double* __restrict__ out_vals,
+                                                                  int* __restrict__ out_mask, int* __restrict__ out_count,
+                                                                  unsigned int* __restrict__ fallbacks) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  C32* buf = reinterpret_cast<C32*>(smem);  // 128 entries: the selectors' scratch
+  const int lane = threadIdx.x, sl = lane & 31, half = lane >> 5;
+  const int q = 2 * blockIdx.x + half;
+  const bool has_q = q < nq;
+  FusePre pre;
+  pre.have[0] = pre.have[1] = true;
+  pre.have[2] = false;
+  pre.id[1] = -1;
+  pre.s[1] = 0.0;
+  if (FUSE && has_q && sl < c1.k) {  // the BM25 list: in flight during the selection
+    pre.id[1] = c1.ids[(size_t)q * c1.k + sl];
+    pre.s[1] = chan_score(c1, q, sl);
+  }
+  const float e_q = has_q ? eps[q] : 0.f;
+  const float margin = 2.f * e_q * margin_scale;
+  bool exact_all = has_q && !(margin == margin && margin <= FLT_MAX);  // no bound for this query
+  // this half's query, spread over its 32 lanes: lane sl holds components 128 u + 4 sl .. + 3
+  tk_v4f qv[8];
+  const int d128 = d >> 7;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const tk_v4f z = {0.f, 0.f, 0.f, 0.f};
+    qv[u] = (has_q && u < d128) ? *reinterpret_cast<const tk_v4f*>(Q + (size_t)q * d + 128 * u + 4 * sl) : z;
+  }
+  // the sum of a value over the 32 lanes of each half, in every lane of the half: five DPP row operations leave the halves'
+  // sums in lanes 31 and 63 (dense_dot.hpp), two v_readlane hand them out — no LDS round trips (ds_bpermute shuffles made
+  // the re-scoring a chain of ~10 of them per candidate)
+  auto half_sum = [&](float v) -> float {
+    v = dpp_add<0x111, 0xf>(v);
+    v = dpp_add<0x112, 0xf>(v);
+    v = dpp_add<0x114, 0xf>(v);
+    v = dpp_add<0x118, 0xf>(v);
+    v = dpp_add<0x142, 0xa>(v);
+    const float s0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+    const float s1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    return half ? s1 : s0;
+  };
+  auto row_load = [&](long r, tk_v4f (&xv)[8]) {
+    const float* xr = X + (size_t)r * d + 4 * sl;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (u < d128) xv[u] = *reinterpret_cast<const tk_v4f*>(xr + 128 * u);
+  };
+  auto row_fma = [&](const tk_v4f (&xv)[8]) -> float {
+    float acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (u < d128) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = fmaf(xv[u][e], qv[u][e], acc);
+      }
+    return half_sum(acc);
+  };
+  auto row_dot = [&](long r) -> float {  // every lane of the half returns <Q[q], X[r]> (r: uniform in the half)
+    tk_v4f xv[8];
+    row_load(r, xv);
+    return row_fma(xv);
+  };
+  C32 out = C32::pad();
+  int need = 0, got = 0;
+  {
+    // (a half without a bound runs the selector on whatever its row holds and discards the result: the other half of the
+    // wave needs its own)
+    const float mg = (has_q && !exact_all) ? margin : 0.f;
+    if (n <= 256)
+      got = select_row_pair_margin<8>(S, ldS, n, q, has_q, kd, mg, lane, buf, out, need);
+    else if (n <= 512)
+      got = select_row_pair_margin<16>(S, ldS, n, q, has_q, kd, mg, lane, buf, out, need);
+    else if (n <= 640)
+      got = select_row_pair_margin<20>(S, ldS, n, q, has_q, kd, mg, lane, buf, out, need);
+    else
+      got = select_row_pair_margin<32>(S, ldS, n, q, has_q, kd, mg, lane, buf, out, need);
+    exact_all = exact_all || (has_q && got < 0);
+    if (exact_all) need = 0;
+  }
+  if (__any(exact_all)) {  // wave-uniform: one of the two halves (or both) re-scores its whole row
+    if (lane == 0 && fallbacks) atomicAdd(fallbacks, (unsigned int)__popcll(__ballot(exact_all && sl == 0)));
+    const C32 keep = out;
+    const int keep_need = need, keep_got = got;
+    // the exact scores of the half's whole row, in LDS (two rows of 1 024 floats behind the selectors' scratch), then the
+    // plain selectors on them
+    float* xs = reinterpret_cast<float*>(buf + 128);
+    for (int r = sl; r < 1024; r += 32) xs[1024 * half + r] = 0.f;
+    wave_lds_fence();
+    for (long r = 0; r < n; ++r) {
+      const float v = row_dot(r);
+      if (exact_all && sl == 0) xs[1024 * half + r] = v;
+    }
+    wave_lds_fence();
+    C32 o2 = C32::pad();
+    int g2 = select_row_pair_any(xs, 1024, n, half, has_q && exact_all, kd, lane, buf, o2);
+    if (g2 < 0) {  // mass ties at the cut among EXACT scores: the staged selector, one half after the other
+      for (int hh = 0; hh < 2; ++hh) {
+        const int qq = 2 * blockIdx.x + hh;
+        const bool mine_h = __shfl((int)exact_all, 32 * hh) != 0;
+        if (qq >= nq || !mine_h) continue;
+        const float* row = xs + 1024 * hh;
+        WaveTopK<C32> tk;
+        tk.init(buf, 128, kd);
+        for (long base = 0; base < n; base += 64) {
+          const long r = base + lane;
+          const bool v = r < n;
+          tk.push_lanes(v ? C32::make(row[r], (u32)r) : C32::pad(), v, lane);
+        }
+        tk.finalize(lane);
+        if (half == hh) {
+          g2 = tk.cnt;
+          o2 = sl < tk.cnt ? tk.buf[sl] : C32::pad();
+        }
+        wave_lds_fence();
+      }
+    }
+    if (exact_all) {  // this half's list is final: exact scores already
+      out = o2;
+      got = g2 < kd ? g2 : kd;
+      need = 0;
+    } else {
+      out = keep;
+      got = keep_got;
+      need = keep_need;
+    }
+  }
+  // ---- exact scores of the candidates (the first `need` survivors of each half), one per step
+  const int steps = __builtin_amdgcn_readfirstlane(max(__shfl(need, 0), __shfl(need, 32)));
+  float mine_exact = 0.f;
+  const int my_id = (int)out.id();
+  for (int c = 0; c < steps; c += 2) {  // two candidates per step: both rows requested before either is summed
+    const int ra = __shfl(my_id, 32 * half + c), rb = __shfl(my_id, 32 * half + (c + 1 < 32 ? c + 1 : 31));
+    const bool la = c < need, lb = c + 1 < need;
+    tk_v4f xa[8], xb[8];
+    row_load(la ? (long)ra : 0, xa);
+    row_load(lb ? (long)rb : 0, xb);
+    const float va = row_fma(xa), vb = row_fma(xb);
+    if (la && sl == c) mine_exact = va;
+    if (lb && sl == c + 1) mine_exact = vb;
+  }
+  if (need > 0) {
+    C32 c = (sl < need) ? C32::make(mine_exact, (u32)out.id()) : C32::pad();
+    c = wave_sortN_desc<C32, 32>(c, lane);
+    out = c;
+    got = need < kd ? need : kd;
+  }
+  const bool v = sl < got && sl < kd;
+  if (has_q && sl < kd) {
+    fin_scores[(size_t)q * kd + sl] = v ? out.score() : -FLT_MAX;
+    fin_ids[(size_t)q * kd + sl] = v ? out.id() : -1ll;
+  }
+  if (FUSE) {
+    pre.id[0] = v ? out.id() : -1ll;
+    pre.s[0] = v ? (double)out.score() : 0.0;
+    ChanIn none;
+    none.ids = nullptr;
+    none.scores = nullptr;
+    none.row2uid = nullptr;
+    none.k = 0;
+    none.is_f64 = 0;
+    fuse_packed_body<32, true>(P, c0, c1, none, nq, max_out, out_ids, out_vals, out_mask, out_count, pre, blockIdx.x * 2);
+  }
+}
+
 // ---- the serving call in ONE launch ------------------------------------------------------------------------------------
 // HybridRetriever.search() issues one query at a time (hybrid_retriever.py:282-384); on a serving corpus (591 / 1 260
 // chunks) its dense + BM25 step was FOUR short launches — BM25 scoring + top-k, one wave per (query, row) of dense scores,
@@ -816,6 +1066,33 @@ int dense_select_fuse_launch(const FuseTail& t, int q0, const float* S, long ldS
   hipLaunchKernelGGL(dense_select_fuse_kernel, dim3((m + 1) / 2), dim3(64), (size_t)cap * sizeof(C32), st, *t.p, S, ldS, n,
                      m, kd, cap, fin_scores, (long long*)fin_ids, c0, c1, mo, (long long*)(t.out_ids + (size_t)q0 * mo),
                      t.out_vals + (size_t)q0 * mo * AMDR_FUSE_NVALS, t.out_mask + (size_t)q0 * mo, t.out_count + q0);
+  AMDR_HIP(hipGetLastError());
+  return AMDR_OK;
+}
+
+// second pass of the two-pass long-batch form (dense_hi_select_fuse_kernel); t == nullptr: the dense lists only
+int dense_hi_select_launch(const FuseTail* t, int q0, const float* S, long ldS, long n, int m, int kd, const float* X,
+                           const float* Q, int d, const float* eps, float* fin_scores, int64_t* fin_ids,
+                           unsigned int* fallbacks, hipStream_t st) {
+  const char* ms = getenv("AMDR_DENSE_SMALL_HI_MARGIN");  // test hook: widens the candidate margin (a huge one: every
+  const float margin_scale = ms ? (float)atof(ms) : 1.f;  // query takes the exact fallback inside the kernel)
+  const size_t lds = 128 * sizeof(C32) + 2 * 1024 * sizeof(float);  // the selectors' scratch + two rows of exact scores
+  if (t) {
+    const int mo = kd + t->kb;
+    ChanIn c0{nullptr, nullptr, (const long long*)t->dense_row2uid, kd, 0};
+    ChanIn c1{(const long long*)(t->kb ? t->bm25_ids + (size_t)q0 * t->kb : nullptr),
+              t->kb ? (const void*)(t->bm25_scores + (size_t)q0 * t->kb) : nullptr, (const long long*)t->bm25_row2uid, t->kb, 1};
+    hipLaunchKernelGGL((dense_hi_select_fuse_kernel<true>), dim3((m + 1) / 2), dim3(64), lds, st, *t->p, S, ldS, n, m, kd, X, Q, d,
+                       eps, margin_scale, fin_scores, (long long*)fin_ids, c0, c1, mo,
+                       (long long*)(t->out_ids + (size_t)q0 * mo), t->out_vals + (size_t)q0 * mo * AMDR_FUSE_NVALS,
+                       t->out_mask + (size_t)q0 * mo, t->out_count + q0, fallbacks);
+  } else {
+    amdr_fuse_params_t P{};
+    ChanIn none{nullptr, nullptr, nullptr, 0, 0};
+    hipLaunchKernelGGL((dense_hi_select_fuse_kernel<false>), dim3((m + 1) / 2), dim3(64), lds, st, P, S, ldS, n, m, kd, X, Q, d,
+                       eps, margin_scale, fin_scores, (long long*)fin_ids, none, none, 0, (long long*)nullptr,
+                       (double*)nullptr, (int*)nullptr, (int*)nullptr, fallbacks);
+  }
   AMDR_HIP(hipGetLastError());
   return AMDR_OK;
 }

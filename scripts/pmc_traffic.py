@@ -28,8 +28,9 @@ sys.path.insert(0, str(ROOT))
 
 # kernel sources an object's traffic depends on: its entry is reported only while THESE files are unchanged
 SOURCES = {
-    "ucc_hybrid": ("dense.hip", "dense_dot.hpp", "dense_panel.hip", "common.hpp"),
-    "dense_only_d384": ("dense.hip", "dense_dot.hpp", "dense_panel.hip", "common.hpp"),
+    "ucc_hybrid": ("dense.hip", "dense_dot.hpp", "dense_panel.hip", "dense_small_hi.hip", "common.hpp"),
+    "ucc_hybrid_second_pass": ("dense.hip", "dense_dot.hpp", "dense_panel.hip", "dense_small_hi.hip", "common.hpp"),
+    "dense_only_d384": ("dense.hip", "dense_dot.hpp", "dense_panel.hip", "dense_small_hi.hip", "common.hpp"),
     "ucc_colbert": ("maxsim.hip", "topk.hpp", "common.hpp"),
     "full_hybrid_rerank": ("maxsim.hip", "topk.hpp", "common.hpp"),
 }
@@ -48,8 +49,11 @@ def sources_fingerprint(key: str) -> str:
 # object -> (command after `python3`, kernels whose traffic is summed, key of the plan string in the command's JSON line)
 OBJECTS = {
     "ucc_hybrid": (["bench.py", "--steps", "5", "--warmup", "1", "--windows", "1", "--no-cpu-baseline", "--no-extras"],
-                   ["dense_panel_scores_kernel"], ("roofline", "plan")),
-    "dense_only_d384": (["bench.py", "--only", "dense_only_d384", "--steps", "5"], ["dense_panel_scores_kernel"],
+                   ["dsh_scores_kernel", "dsh_split_queries_kernel"], ("roofline", "plan")),
+    "ucc_hybrid_second_pass": (["bench.py", "--steps", "5", "--warmup", "1", "--windows", "1", "--no-cpu-baseline", "--no-extras"],
+                               ["dense_hi_select_fuse_kernel", "bm25_score_topk_kernel"], ("roofline", "plan")),
+    "dense_only_d384": (["bench.py", "--only", "dense_only_d384", "--steps", "5"],
+                        ["dsh_scores_kernel", "dsh_split_queries_kernel"],
                         ("dense_only_d384", "tiled_batch", "roofline", "plan")),
     "ucc_colbert": (["bench.py", "--only", "ucc_colbert", "--steps", "5"],
                     ["maxsim_hi2_ring_kernel", "maxsim_select_kernel", "maxsim_rescore_ring_kernel", "maxsim_rescore_kernel",
