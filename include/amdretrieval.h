@@ -265,13 +265,15 @@ int amdr_hybrid_small_device(amdr_dense_t* dense, amdr_bm25_t* bm25, const float
                              int64_t* dense_ids_dev, double* bm25_scores_dev, int64_t* bm25_ids_dev, int64_t* out_ids,
                              double* out_vals, int32_t* out_mask, int32_t* out_count, void* stream);
 
-/* EXPERIMENTAL (round 4; not on the product's search path yet): the first half of a two-pass form of the long-batch dense
- * channel on a short corpus (search_dense over a batch, hybrid_retriever.py:181-189).  approx_device writes, for every
+/* The first pass of the two-pass form of the long-batch dense channel on a short corpus (search_dense over a batch,
+ * hybrid_retriever.py:181-189) — what amdr_dense_search_device / amdr_dense_search_fuse_device run inside from 4 096
+ * queries per launch on <= 1 024 rows with d a multiple of 128 and k (+ the BM25 depth) <= 32 (AMDR_DENSE_SMALL_HI=0: the
+ * exact fp32 form), exported for tests and measurements.  approx_device writes, for every
  * query and chunk row, the dot product of the fp16 roundings of the scaled operands — S[nq, ldS] (ldS >= the rows padded to
  * 32, a multiple of 4; columns [n, padded) are 0) — on the fp16 matrix instructions, and per query the PROVEN bound
  * eps[q] >= |S[q][r] - <Q[q], X[r]>| for every row r (NaN: a non-finite query or one outside the scale range — no bound),
- * in the units of the exact score.  A second pass that re-scores the rows with S >= (k-th best of S) - 2 eps exactly returns
- * the exact top-k.  create takes the statistics and the fp16 image of the dense handle's matrix as it is NOW (rows added
+ * in the units of the exact score.  The second pass (inside the search calls) re-scores the rows with
+ * S >= (k-th best of S) - 2 eps in exact fp32 and ranks them: the exact top-k, ties to the lower row.  create takes the statistics and the fp16 image of the dense handle's matrix as it is NOW (rows added
  * later are not seen); d must be a multiple of 128 in [128, 1024]; the dense handle must outlive this one. */
 int amdr_dense_small_create(amdr_dense_t* dense, amdr_dense_small_t** out);
 int amdr_dense_small_approx_device(amdr_dense_small_t* h, const float* Q_dev, int32_t nq, float* S_dev, int64_t ldS,

@@ -605,8 +605,9 @@ def rerank_blend_device(nq: int, max_out: int, count: int, ids: int, vals: int, 
 
 
 class DenseSmallApprox:
-    """EXPERIMENTAL: fp16 first pass over a short corpus (amdr_dense_small_*): approximate scores of every (query, row)
-    with a proven per-query bound on their distance from the exact dot product.  Not on the search path."""
+    """The fp16 first pass over a short corpus on its own (amdr_dense_small_*; tests and measurements — the search calls
+    run it inside): approximate scores of every (query, row) with a proven per-query bound on their distance from the
+    exact dot product."""
 
     def __init__(self, dense: "DenseIndex"):
         self._h = C.c_void_p()

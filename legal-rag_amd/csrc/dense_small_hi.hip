@@ -2,8 +2,8 @@
 // chunks x 768 dims, hybrid_retriever.py:181-189 search_dense over a batch): approximate scores of every (query, chunk)
 // on the fp16 matrix instructions, 16 x the rate of the exact fp32 form that dense_panel.hip runs at 0.80 of its peak, with
 // the PROVEN bound of dense_hi.hip on their distance from the exact dot product — what a second pass needs to re-score only
-// the chunks within 2 eps of a query's k-th best.  Round 4 builds and measures THIS half; the product's
-// search path does not call it yet.
+// the chunks within 2 eps of a query's k-th best (fuse.hip dense_hi_select_fuse_kernel; dense.hip run_search_batched takes
+// the pair from 4 096 queries per launch).
 //
 //   amdr_dense_small_create        statistics of the chunk matrix (largest component -> power-of-two scale, largest row
 //                                  norm) and its fp16 image  Xh[K slice][row][128 halves]  (rows padded to 32, zero)
