@@ -171,9 +171,17 @@ __global__ __launch_bounds__(kDsWaves * 64) __attribute__((amdgpu_waves_per_eu(2
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r32 = lane & 31, h = lane >> 5;
   const int n_qtiles = (nq + 31) >> 5;
-  const int ta = (blockIdx.x * kDsWaves + wave) * 2, tb = ta + 1;
+  // Block -> (query group, chunk group), XCD-aware: consecutive workgroup ids go round the 8 XCDs, each with its own L2, and
+  // the chunk groups of ONE query group re-read the same 384 KB of query fragments — so they take consecutive slots of the
+  // SAME XCD (b % 8) and the fragments come from that L2 after the first of them.  In (x = query group, y = chunk group)
+  // order the fabric carried the query image once per chunk group: 297 MB of reads per 37 376 x 591 launch for 57 MB.
+  const int n_groups = (n_tiles + kDsG - 1) / kDsG;
+  const int b = blockIdx.x, slot = b >> 3;
+  const int qg = (slot / n_groups) * 8 + (b & 7), yg = slot % n_groups;
+  const int ta = (qg * kDsWaves + wave) * 2, tb = ta + 1;
+  if (qg * kDsWaves * 2 >= n_qtiles) return;  // (block-uniform: the grid is rounded up to 8 query groups)
   const int la = ta < n_qtiles ? ta : 0, lb = tb < n_qtiles ? tb : 0;  // (a dead tile loads tile 0's fragments, stores nothing)
-  const int t0 = blockIdx.y * kDsG;
+  const int t0 = yg * kDsG;
   const int g = n_tiles - t0 < kDsG ? n_tiles - t0 : kDsG;  // block-uniform, >= 1
 
   // DMA role: pieces 2 wave, 2 wave + 1 of a tile's 8 (1 KiB = 4 rows of 256 B); lane l: row + (l >> 4), PHYSICAL slot
@@ -398,7 +406,8 @@ int amdr_dense_small_approx_device(amdr_dense_small_t* h, const float* Q_dev, in
                      h->row_norm_max * h->x_scale, 1.f / h->x_scale, eps_dev);
   constexpr int NBUF = 4;
   AMDR_HIP(hipFuncSetAttribute((const void*)dsh_scores_kernel<NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, NBUF * kDsStage));
-  hipLaunchKernelGGL((dsh_scores_kernel<NBUF>), dim3(ceil_div(n_qtiles, 2 * kDsWaves), ceil_div(n_tiles, kDsG)), dim3(kDsWaves * 64),
+  const int qgroups8 = ceil_div(ceil_div(n_qtiles, 2 * kDsWaves), 8) * 8;
+  hipLaunchKernelGGL((dsh_scores_kernel<NBUF>), dim3(qgroups8 * ceil_div(n_tiles, kDsG)), dim3(kDsWaves * 64),
                      NBUF * kDsStage, st, h->img.as<unsigned char>(), (long)h->n_pad, n_tiles, ks, Qh, nq, q_unscale,
                      1.f / h->x_scale, S_dev, (long)ldS);
   AMDR_HIP(hipGetLastError());
