@@ -48,8 +48,10 @@ def main():
         f"windows {', '.join(f'{x:.4f}' for x in un['timing']['ms_per_step'])} ms after {un['warmup']} untimed warm-up steps; roofline "
         f"{un['roofline']['frac']:.3f} = HIP events over the launches of the median window, traffic {un['roofline']['traffic'] / 1e6:.1f} MB per "
         "launch from `profiles/pmc_traffic.json`).\n\n"
-        "What the grids are: `131072` (512 persistent blocks x 256 threads) / `64x37376` / `1196032` = the timed UCC-en hybrid step "
-        "(dense_panel_scores, bm25_score_topk, dense_select_fuse); `64000` / `64x1168` / `37376` = the same on the un-tiled 1 168-query set; "
+        "What the grids are: `dsh_split_queries_kernel` 299008 + `dsh_scores_kernel` 194560 + `dense_hi_select_fuse_kernel` 1196032 + "
+        "`bm25_score_topk_kernel` 64x37376 = the timed UCC-en hybrid step in its two-pass form (DESIGN.md 4.11); "
+        "`dense_panel_scores_kernel` 131072 + `dense_select_fuse_kernel` 1196032 = the same step's exact form (`exact_form`, "
+        "AMDR_DENSE_SMALL_HI=0) and the d = 384 object's warm-up; `64000` / `64x1168` / `37376` = the un-tiled 1 168-query set; "
         "`hybrid_small_kernel` = the B = 1 latency loop (one launch per query); `37376x25` and `74752` (MaxSim) = `ucc_colbert` / "
         "`full_hybrid_rerank`; `dense_hi_tilemax_kernel<12|16, true|false>` + `dense_hi_*` + `dense_rescore_tiles` + `dense_final_topk` = "
         "the large scans (`hbm_scan`, `hbm_scan_d1024`, `shard8_proxy`); `shard_pack_kernel` / `shard_merge_kernel` = the exchange at "
@@ -103,8 +105,10 @@ def main():
                  "and the candidate lists); the 1/8-shard proxy 4.09 GB for 3.84 (sample 0.13 + re-scoring 0.08 beside the scan's 3.875); "
                  "the 256-query search = four scans in one launch, 15.9 GB for 15.36.  MaxSim per UCC-en batch: pass 1 0.45 GB for a 24.3-MB "
                  "hi image read by 146 query groups (3.5 GB of LDS-DMA fills: 87 % L2 hits), re-scoring 0.35 GB (round 3: 0.93), split "
-                 "0.04 GB (18 MB of query images written).  The headline's dense kernel: 0.360 GB per launch for 0.205 algorithmic (the "
-                 "score matrix is 91 MB of it; the query tile is re-read per row part).\n")
+                 "0.04 GB (18 MB of query images written).  The headline's first pass (split + scores): 0.342 GB per launch — 115 MB of "
+                 "queries read, 57 MB of fp16 fragments written and read back (once per query group: the chunk groups of a query "
+                 "group run on one XCD), 91 MB of scores written; its second pass 0.33 GB (scores, queries and BM25 lists in, "
+                 "dense lists and fusion outputs out).\n")
     for title, d, filt in (("## 2. SQ counters, MaxSim (`scripts/pmc_sq.sh ucc_colbert`, EXTRA=1; per launch, summed over the chip)", a.sq, "maxsim"),
                            ("## 3. SQ counters, BM25 in the headline step (`scripts/pmc_sq.sh headline r4/sq_bm25 bm25`)", a.sq_bm25, "bm25")):
         if not d:
