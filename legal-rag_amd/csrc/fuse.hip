@@ -624,7 +624,7 @@ __device__ __forceinline__ int select_row_pair_margin(const float* __restrict__ 
   return cnt;
 }
 
-template <bool FUSE>
+template <bool FUSE, int D128>  // D128 = d / 128 (the row a half-wave re-scores: D128 16-byte pieces per lane)
 __global__ __launch_bounds__(64) void dense_hi_select_fuse_kernel(amdr_fuse_params_t P, const float* __restrict__ S, long ldS, long n,
                                                                   int nq, int kd, const float* __restrict__ X,
                                                                   const float* __restrict__ Q, int d,
@@ -652,12 +652,11 @@ __global__ __launch_bounds__(64) void dense_hi_select_fuse_kernel(amdr_fuse_para
   const float margin = 2.f * e_q * margin_scale;
   bool exact_all = has_q && !(margin == margin && margin <= FLT_MAX);  // no bound for this query
   // this half's query, spread over its 32 lanes: lane sl holds components 128 u + 4 sl .. + 3
-  tk_v4f qv[8];
-  const int d128 = d >> 7;
+  tk_v4f qv[D128];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
+  for (int u = 0; u < D128; ++u) {
     const tk_v4f z = {0.f, 0.f, 0.f, 0.f};
-    qv[u] = (has_q && u < d128) ? *reinterpret_cast<const tk_v4f*>(Q + (size_t)q * d + 128 * u + 4 * sl) : z;
+    qv[u] = has_q ? *reinterpret_cast<const tk_v4f*>(Q + (size_t)q * d + 128 * u + 4 * sl) : z;
   }
   // the sum of a value over the 32 lanes of each half, in every lane of the half: five DPP row operations leave the halves'
   // sums in lanes 31 and 63 (dense_dot.hpp), two v_readlane hand them out — no LDS round trips (ds_bpermute shuffles made
@@ -672,24 +671,21 @@ __global__ __launch_bounds__(64) void dense_hi_select_fuse_kernel(amdr_fuse_para
     const float s1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
     return half ? s1 : s0;
   };
-  auto row_load = [&](long r, tk_v4f (&xv)[8]) {
+  auto row_load = [&](long r, tk_v4f (&xv)[D128]) {
     const float* xr = X + (size_t)r * d + 4 * sl;
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (u < d128) xv[u] = *reinterpret_cast<const tk_v4f*>(xr + 128 * u);
+    for (int u = 0; u < D128; ++u) xv[u] = *reinterpret_cast<const tk_v4f*>(xr + 128 * u);
   };
-  auto row_fma = [&](const tk_v4f (&xv)[8]) -> float {
+  auto row_fma = [&](const tk_v4f (&xv)[D128]) -> float {
     float acc = 0.f;
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (u < d128) {
+    for (int u = 0; u < D128; ++u)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = fmaf(xv[u][e], qv[u][e], acc);
-      }
+      for (int e = 0; e < 4; ++e) acc = fmaf(xv[u][e], qv[u][e], acc);
     return half_sum(acc);
   };
   auto row_dot = [&](long r) -> float {  // every lane of the half returns <Q[q], X[r]> (r: uniform in the half)
-    tk_v4f xv[8];
+    tk_v4f xv[D128];
     row_load(r, xv);
     return row_fma(xv);
   };
@@ -761,12 +757,18 @@ __global__ __launch_bounds__(64) void dense_hi_select_fuse_kernel(amdr_fuse_para
   const int steps = __builtin_amdgcn_readfirstlane(max(__shfl(need, 0), __shfl(need, 32)));
   float mine_exact = 0.f;
   const int my_id = (int)out.id();
-  for (int c = 0; c < steps; c += 2) {  // two candidates per step: both rows requested before either is summed
-    const int ra = __shfl(my_id, 32 * half + c), rb = __shfl(my_id, 32 * half + (c + 1 < 32 ? c + 1 : 31));
+  // two candidates per step: both rows requested before either is summed.  (Tried: the NEXT step's rows requested before
+  // this step's are summed, two register sets in ping-pong — 146 VGPRs, three waves per SIMD instead of four: 119.5 against
+  // 119.1 us; the kernel issues 2 289 vector instructions per wave = 56 % of its time and waits on memory for half of it.)
+  for (int c = 0; c < steps; c += 2) {  // (steps: wave-uniform)
+    // candidates c, c + 1 of each half: their lanes are wave-uniform (v_readlane), the half picks its own
+    const int c1 = c + 1 < 32 ? c + 1 : 31;
+    const int ra0 = __builtin_amdgcn_readlane(my_id, c), ra1 = __builtin_amdgcn_readlane(my_id, 32 + c);
+    const int rb0 = __builtin_amdgcn_readlane(my_id, c1), rb1 = __builtin_amdgcn_readlane(my_id, 32 + c1);
     const bool la = c < need, lb = c + 1 < need;
-    tk_v4f xa[8], xb[8];
-    row_load(la ? (long)ra : 0, xa);
-    row_load(lb ? (long)rb : 0, xb);
+    tk_v4f xa[D128], xb[D128];
+    row_load(la ? (long)(half ? ra1 : ra0) : 0, xa);
+    row_load(lb ? (long)(half ? rb1 : rb0) : 0, xb);
     const float va = row_fma(xa), vb = row_fma(xb);
     if (la && sl == c) mine_exact = va;
     if (lb && sl == c + 1) mine_exact = vb;
@@ -1082,16 +1084,40 @@ int dense_hi_select_launch(const FuseTail* t, int q0, const float* S, long ldS, 
     ChanIn c0{nullptr, nullptr, (const long long*)t->dense_row2uid, kd, 0};
     ChanIn c1{(const long long*)(t->kb ? t->bm25_ids + (size_t)q0 * t->kb : nullptr),
               t->kb ? (const void*)(t->bm25_scores + (size_t)q0 * t->kb) : nullptr, (const long long*)t->bm25_row2uid, t->kb, 1};
-    hipLaunchKernelGGL((dense_hi_select_fuse_kernel<true>), dim3((m + 1) / 2), dim3(64), lds, st, *t->p, S, ldS, n, m, kd, X, Q, d,
-                       eps, margin_scale, fin_scores, (long long*)fin_ids, c0, c1, mo,
-                       (long long*)(t->out_ids + (size_t)q0 * mo), t->out_vals + (size_t)q0 * mo * AMDR_FUSE_NVALS,
-                       t->out_mask + (size_t)q0 * mo, t->out_count + q0, fallbacks);
+#define AMDR_HSF_FUSED(D)                                                                                                  \
+  hipLaunchKernelGGL((dense_hi_select_fuse_kernel<true, D>), dim3((m + 1) / 2), dim3(64), lds, st, *t->p, S, ldS, n, m, kd, X, \
+                     Q, d, eps, margin_scale, fin_scores, (long long*)fin_ids, c0, c1, mo,                                 \
+                     (long long*)(t->out_ids + (size_t)q0 * mo), t->out_vals + (size_t)q0 * mo * AMDR_FUSE_NVALS,          \
+                     t->out_mask + (size_t)q0 * mo, t->out_count + q0, fallbacks)
+    switch (d >> 7) {
+      case 1: AMDR_HSF_FUSED(1); break;
+      case 2: AMDR_HSF_FUSED(2); break;
+      case 3: AMDR_HSF_FUSED(3); break;
+      case 4: AMDR_HSF_FUSED(4); break;
+      case 5: AMDR_HSF_FUSED(5); break;
+      case 6: AMDR_HSF_FUSED(6); break;
+      case 7: AMDR_HSF_FUSED(7); break;
+      default: AMDR_HSF_FUSED(8); break;
+    }
+#undef AMDR_HSF_FUSED
   } else {
     amdr_fuse_params_t P{};
     ChanIn none{nullptr, nullptr, nullptr, 0, 0};
-    hipLaunchKernelGGL((dense_hi_select_fuse_kernel<false>), dim3((m + 1) / 2), dim3(64), lds, st, P, S, ldS, n, m, kd, X, Q, d,
-                       eps, margin_scale, fin_scores, (long long*)fin_ids, none, none, 0, (long long*)nullptr,
-                       (double*)nullptr, (int*)nullptr, (int*)nullptr, fallbacks);
+#define AMDR_HSF_PLAIN(D)                                                                                                   \
+  hipLaunchKernelGGL((dense_hi_select_fuse_kernel<false, D>), dim3((m + 1) / 2), dim3(64), lds, st, P, S, ldS, n, m, kd, X, Q, \
+                     d, eps, margin_scale, fin_scores, (long long*)fin_ids, none, none, 0, (long long*)nullptr,             \
+                     (double*)nullptr, (int*)nullptr, (int*)nullptr, fallbacks)
+    switch (d >> 7) {
+      case 1: AMDR_HSF_PLAIN(1); break;
+      case 2: AMDR_HSF_PLAIN(2); break;
+      case 3: AMDR_HSF_PLAIN(3); break;
+      case 4: AMDR_HSF_PLAIN(4); break;
+      case 5: AMDR_HSF_PLAIN(5); break;
+      case 6: AMDR_HSF_PLAIN(6); break;
+      case 7: AMDR_HSF_PLAIN(7); break;
+      default: AMDR_HSF_PLAIN(8); break;
+    }
+#undef AMDR_HSF_PLAIN
   }
   AMDR_HIP(hipGetLastError());
   return AMDR_OK;
