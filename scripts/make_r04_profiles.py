@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--sq", default=None)
     ap.add_argument("--sq-bm25", default=None)
     ap.add_argument("--hs", default=None)
+    ap.add_argument("--sq-second", default=None)
     a = ap.parse_args()
     F = ROOT / a.final
     # ---- bench lines
@@ -110,7 +111,10 @@ def main():
                  "group run on one XCD), 91 MB of scores written; its second pass 0.33 GB (scores, queries and BM25 lists in, "
                  "dense lists and fusion outputs out).\n")
     for title, d, filt in (("## 2. SQ counters, MaxSim (`scripts/pmc_sq.sh ucc_colbert`, EXTRA=1; per launch, summed over the chip)", a.sq, "maxsim"),
-                           ("## 3. SQ counters, BM25 in the headline step (`scripts/pmc_sq.sh headline r4/sq_bm25 bm25`)", a.sq_bm25, "bm25")):
+                           ("## 3. SQ counters, BM25 in the headline step (`scripts/pmc_sq.sh headline r4/sq_bm25 bm25`)", a.sq_bm25, "bm25"),
+                           ("## 4. SQ counters, the second pass of the headline's dense channel (`scripts/pmc_sq.sh headline r4/sq_b "
+                            "dense_hi_select`; measured before the row length became a template parameter: 125 us)", a.sq_second,
+                            "dense_hi_select")):
         if not d:
             continue
         lines.append(title)
