@@ -267,7 +267,7 @@ int amdr_hybrid_small_device(amdr_dense_t* dense, amdr_bm25_t* bm25, const float
 
 /* The first pass of the two-pass form of the long-batch dense channel on a short corpus (search_dense over a batch,
  * hybrid_retriever.py:181-189) — what amdr_dense_search_device / amdr_dense_search_fuse_device run inside from 4 096
- * queries per launch on <= 1 024 rows with d a multiple of 128 and k (+ the BM25 depth) <= 32 (AMDR_DENSE_SMALL_HI=0: the
+ * queries per launch on <= 1 024 rows with d a multiple of 128 and k <= 12 (AMDR_DENSE_SMALL_HI=0: the
  * exact fp32 form), exported for tests and measurements.  approx_device writes, for every
  * query and chunk row, the dot product of the fp16 roundings of the scaled operands — S[nq, ldS] (ldS >= the rows padded to
  * 32, a multiple of 4; columns [n, padded) are 0) — on the fp16 matrix instructions, and per query the PROVEN bound

@@ -409,7 +409,11 @@ bool small_hi_shape(const amdr_dense* h, int m, int k, int kb) {
   if (e && e[0] == '0') return false;
   const char* mn = getenv("AMDR_DENSE_SMALL_HI_MIN");
   const int m_min = mn && atoi(mn) > 0 ? atoi(mn) : 4096;
-  return m >= m_min && h->n >= 1 && h->n <= 1024 && h->d >= 128 && h->d <= 1024 && h->d % 128 == 0 && k >= 1 && k + kb <= 32;
+  // depth <= 12: the second pass finds its candidates with the pair selector's 32 slots per query; from k ~ 14 up those
+  // overflow on most queries and the query re-scores its whole row (37 376 queries on 1 024 x 768: k = 12 230 against 517 us
+  // for the exact form, k = 14 465 against 536, k = 20 2 099 against 619)
+  return m >= m_min && h->n >= 1 && h->n <= 1024 && h->d >= 128 && h->d <= 1024 && h->d % 128 == 0 && k >= 1 && k <= 12 &&
+         k + kb <= 32;
 }
 // the image and the workspaces of that form; false: not available now (creation failed before, non-finite matrix, or a
 // stream is capturing and nothing was reserved) — the caller takes the exact form
@@ -1203,7 +1207,7 @@ int amdr_dense_reserve(amdr_dense_t* h, int32_t nq_max, int32_t k_max) {
   }
   if ((rc = h->qbuf.ensure((size_t)nq_max * h->d * sizeof(float)))) return rc;
   if ((rc = h->sbuf.ensure((size_t)nq_max * k_max * sizeof(float)))) return rc;
-  if (small_hi_shape(h, nq_max, k_max < 16 ? k_max : 16, 0))  // (so that a later capture finds the two-pass form's buffers)
+  if (small_hi_shape(h, nq_max, k_max < 12 ? k_max : 12, 0))  // (so that a later capture finds the two-pass form's buffers)
     (void)small_hi_ready(h, batched_chunk(h, nq_max) < nq_max ? batched_chunk(h, nq_max) : nq_max, nullptr);
   return h->ibuf.ensure((size_t)nq_max * k_max * sizeof(int64_t));
 }

@@ -548,10 +548,9 @@ __global__ __launch_bounds__(64) void dense_select_fuse_kernel(amdr_fuse_params_
 // ---- second pass of the two-pass long-batch dense form (round 4; first pass: dense_small_hi.hip) -----------------------
 // S holds APPROXIMATE scores (fp16 roundings of both operands, exact products, fp32 sums) and eps[q] the proven bound on
 // their distance from the exact dot products.  Per query (two per wave, a half-wave each, as dense_select_fuse_kernel):
-//   1. the rows whose approximate score reaches (k-th best lane maximum) - 2 eps — a superset of the rows within 2 eps of
-//      the k-th best approximate score, hence of every row that can be in the exact top-k — by the pair selector's own
-//      machinery with the threshold lowered by the margin; sorted by approximate score, cut back to the rows at or above
-//      (k-th best approximate score) - 2 eps;
+//   1. the pair selector's first stage (rows at or above the k-th best lane maximum, sorted: the first k are the k best
+//      approximate scores), then the rows at or above (k-th best approximate score) - 2 eps — every row that can be in the
+//      exact top-k: a prefix of that list, or one more sweep of the row when the margin reaches below the first threshold;
 //   2. their EXACT fp32 dot products, one candidate at a time, the half-wave's 32 lanes across the row (512-byte loads, a
 //      butterfly sum);
 //   3. sorted by (exact score, lower id first): the dense channel's top-k — then the fusion, as before.
@@ -582,45 +581,61 @@ __device__ __forceinline__ int select_row_pair_margin(const float* __restrict__ 
 #pragma unroll
   for (int v = 0; v < V; ++v) lb.c = sk[v] > lb.c ? sk[v] : lb.c;
   const K32 sorted_best = wave_sortN_desc<K32, 32>(lb, lane);
-  const int src = (lane & 32) + (k - 1 < 31 ? k - 1 : 31);
-  const u32 T = (u32)__shfl((int)sorted_best.c, src);  // k-th lane best of this half: <= the k-th best score
-  u32 Te = 1u;                                          // (T == 0: fewer than k rows — every row is a candidate)
-  if (T > 1u) {
-    const float tf = unord32(T) - margin;  // (a NaN margin never gets here: the caller takes the exact path)
-    Te = ord32(tf);
-    Te = Te > 1u ? Te : 1u;
-  }
-  int mine = 0;
-#pragma unroll
-  for (int v = 0; v < V; ++v) mine += (sk[v] >= Te) ? 1 : 0;
-  int incl = mine;
-#pragma unroll
-  for (int sft = 1; sft < 32; sft <<= 1) {
-    const int o = __shfl_up(incl, sft, 32);
-    incl += (j >= sft) ? o : 0;
-  }
-  const int cnt = __shfl(incl, (lane & 32) + 31);
-  if (cnt > 32) return -1;  // (this lane's half; the caller votes)
-  int at = (lane & 32) + incl - mine;
-#pragma unroll
-  for (int v = 0; v < V; ++v) {
-    if (sk[v] >= Te) {
-      C32 c;
-      c.c = ((u64)sk[v] << 32) | (u64)(0xffffffffu - (u32)(128 * (v >> 2) + 4 * j + (v & 3)));
-      scratch[at++] = c;
-    }
-  }
-  wave_lds_fence();
-  C32 c = (j < cnt) ? scratch[lane] : C32::pad();
-  c = wave_sortN_desc<C32, 32>(c, lane);
-  wave_lds_fence();
-  out = c;
-  // the rows at or above (k-th best approximate score) - margin: a prefix of the sorted survivors
   const int kk = (k - 1 < 31 ? k - 1 : 31);
-  const float tk_f = __shfl(c.score(), (lane & 32) + kk);
-  const bool in = j < cnt && (cnt <= kk || c.score() >= tk_f - margin);
-  const unsigned long long m = __ballot(in);
-  need = __popcll((lane & 32) ? (m >> 32) : (m & 0xffffffffull));
+  const u32 T = (u32)__shfl((int)sorted_best.c, (lane & 32) + kk);  // k-th lane best of this half: <= the k-th best score
+  // the rows at or above a key threshold -> this half's 32 scratch slots, sorted into the lanes; -1: more than 32
+  auto gather = [&](u32 Te, C32& c) -> int {
+    int mine = 0;
+#pragma unroll
+    for (int v = 0; v < V; ++v) mine += (sk[v] >= Te) ? 1 : 0;
+    int incl = mine;
+#pragma unroll
+    for (int sft = 1; sft < 32; sft <<= 1) {
+      const int o = __shfl_up(incl, sft, 32);
+      incl += (j >= sft) ? o : 0;
+    }
+    const int cnt = __shfl(incl, (lane & 32) + 31);
+    if (cnt > 32) return -1;
+    int at = (lane & 32) + incl - mine;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      if (sk[v] >= Te) {
+        C32 e;
+        e.c = ((u64)sk[v] << 32) | (u64)(0xffffffffu - (u32)(128 * (v >> 2) + 4 * j + (v & 3)));
+        scratch[at++] = e;
+      }
+    }
+    wave_lds_fence();
+    c = (j < cnt) ? scratch[lane] : C32::pad();
+    c = wave_sortN_desc<C32, 32>(c, lane);
+    wave_lds_fence();
+    return cnt;
+  };
+  // stage 1, the exact form's own selection: the rows at or above the k-th LANE maximum (a few more than k: its first k
+  // are the k best approximate scores).  With the margin already taken off that threshold (the first version), depths from
+  // ~14 up had more than 32 survivors on most queries and fell back to re-scoring the whole row: 732 against 559 us at
+  // k = 16, 3.4 against 0.6 ms at k = 20 (1 024 x 768, 37 376 queries).
+  const u32 Te1 = T > 1u ? T : 1u;  // (T == 0: fewer than k rows — every row)
+  C32 c;
+  int cnt = gather(Te1, c);
+  if (cnt < 0) return -1;  // (this lane's half; the caller votes)
+  // stage 2: everything at or above (k-th best approximate score) - margin.  Usually a prefix of the sorted survivors;
+  // when the margin reaches below the lane-maximum threshold the row is swept again with the cut itself.
+  u32 cut = 1u;
+  if (cnt > kk) {
+    const float tk_f = __shfl(c.score(), (lane & 32) + kk);
+    cut = ord32(tk_f - margin);
+    cut = cut > 1u ? cut : 1u;
+  }
+  if (cut < Te1) {  // (half-uniform)
+    cnt = gather(cut, c);
+    if (cnt < 0) return -1;
+    need = cnt;
+  } else {
+    const unsigned long long m = __ballot(j < cnt && (u32)(c.c >> 32) >= cut);
+    need = __popcll((lane & 32) ? (m >> 32) : (m & 0xffffffffull));
+  }
+  out = c;
   return cnt;
 }
 

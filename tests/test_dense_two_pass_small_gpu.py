@@ -33,8 +33,8 @@ def _search(idx, Q, k, env):
                 os.environ[n] = v
 
 
-@pytest.mark.parametrize("n,d,nq,k", [(591, 768, 4100, 10), (1024, 384, 300, 16), (33, 128, 129, 5), (640, 1024, 200, 1),
-                                      (257, 256, 513, 32)])
+@pytest.mark.parametrize("n,d,nq,k", [(591, 768, 4100, 10), (1024, 384, 300, 12), (33, 128, 129, 5), (640, 1024, 200, 1),
+                                      (257, 256, 513, 11)])
 def test_two_pass_equals_the_exact_form_and_the_oracle(n, d, nq, k):
     from legal_rag_amd import _native
     from oracle import dense as OD
@@ -53,6 +53,20 @@ def test_two_pass_equals_the_exact_form_and_the_oracle(n, d, nq, k):
     for s, i, what in ((s2, i2, "two-pass"), (sf, i_f, "fallback"), (s1, i1, "exact")):
         assert np.array_equal(i, ei), what
         assert np.max(np.abs(s - es)) <= TOL, what
+    idx.close()
+
+
+def test_deep_searches_keep_the_exact_form():
+    """Beyond depth 12 the second pass's 32 candidate slots per query overflow too often: those searches take the exact form."""
+    from legal_rag_amd import _native
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((300, 256)).astype(np.float32)
+    idx = _native.DenseIndex(X, device=0)
+    two = {"AMDR_DENSE_SMALL_HI": "1", "AMDR_DENSE_SMALL_HI_MIN": "96"}
+    Q = rng.standard_normal((200, 256)).astype(np.float32)
+    assert _search(idx, Q, 12, two)[2].startswith("dsh_scores_kernel")
+    for k in (13, 16, 32):
+        assert not _search(idx, Q, k, two)[2].startswith("dsh_scores_kernel")
     idx.close()
 
 
