@@ -1139,6 +1139,8 @@ def main():
                     "fused_ids_equal_the_resident_step": same_ids, "blob_bytes": len(blob)}
             except Exception as e:  # noqa: BLE001 - report, never hide
                 result["with_tokenisation"] = {"error": repr(e)}
+        if rank == 0 and plan.startswith("dsh_scores_kernel"):
+            result["two_pass_exact_fallback_queries"] = R.dense.two_pass_fallbacks()  # of every two-pass step so far
         if rank == 0 and shard == "queries" and plan.startswith("dsh_scores_kernel"):
             # the same step with the dense channel's EXACT long-batch form (AMDR_DENSE_SMALL_HI=0: dense_panel_scores_kernel on
             # the fp32 matrix instructions + dense_select_fuse_kernel) — what `value` was measured on in rounds 1-3

@@ -275,6 +275,10 @@ int amdr_hybrid_small_device(amdr_dense_t* dense, amdr_bm25_t* bm25, const float
  * in the units of the exact score.  The second pass (inside the search calls) re-scores the rows with
  * S >= (k-th best of S) - 2 eps in exact fp32 and ranks them: the exact top-k, ties to the lower row.  create takes the statistics and the fp16 image of the dense handle's matrix as it is NOW (rows added
  * later are not seen); d must be a multiple of 128 in [128, 1024]; the dense handle must outlive this one. */
+/* queries of this handle's two-pass searches so far that re-scored their WHOLE row inside the second pass (more than 32 rows
+ * inside the margin, or no bound for the query): the results are exact either way, a large share means the data does not suit
+ * the form (AMDR_DENSE_SMALL_HI=0).  Synchronises with the device. */
+int amdr_dense_two_pass_fallbacks(amdr_dense_t* h, int64_t* out);
 int amdr_dense_small_create(amdr_dense_t* dense, amdr_dense_small_t** out);
 int amdr_dense_small_approx_device(amdr_dense_small_t* h, const float* Q_dev, int32_t nq, float* S_dev, int64_t ldS,
                                    float* eps_dev /* nullable [nq] */, void* stream);

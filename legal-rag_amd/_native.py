@@ -29,7 +29,7 @@ FV = dict(score=0, rrf_norm=1, weighted_sum=2, dense_norm=3, bm25_norm=4, colber
 EXPORTS = (
     "amdr_last_error", "amdr_version", "amdr_device_count", "amdr_device_name",
     "amdr_dense_create", "amdr_dense_create_from_device", "amdr_dense_add", "amdr_dense_ntotal", "amdr_dense_dim",
-    "amdr_dense_reserve", "amdr_dense_search", "amdr_dense_search_device", "amdr_dense_search_fuse_device", "amdr_hybrid_small_device", "amdr_dense_small_create", "amdr_dense_small_approx_device", "amdr_dense_small_destroy", "amdr_dense_read_rows", "amdr_dense_score_rows",
+    "amdr_dense_reserve", "amdr_dense_search", "amdr_dense_search_device", "amdr_dense_search_fuse_device", "amdr_hybrid_small_device", "amdr_dense_small_create", "amdr_dense_small_approx_device", "amdr_dense_small_destroy", "amdr_dense_two_pass_fallbacks", "amdr_dense_read_rows", "amdr_dense_score_rows",
     "amdr_dense_plan_info", "amdr_dense_workspace_plan", "amdr_dense_hi_counters", "amdr_dense_profile_begin", "amdr_dense_profile_end", "amdr_dense_destroy",
     "amdr_bm25_create", "amdr_bm25_ndocs", "amdr_bm25_reserve", "amdr_bm25_search", "amdr_bm25_search_device",
     "amdr_bm25_scores", "amdr_bm25_destroy",
@@ -50,7 +50,7 @@ SIGNATURES = {
     "amdr_last_error": "", "amdr_version": "", "amdr_device_count": "P", "amdr_device_name": "iPi",
     "amdr_dense_create": "PliiP", "amdr_dense_create_from_device": "PliiP", "amdr_dense_add": "PPl",
     "amdr_dense_ntotal": "PP", "amdr_dense_dim": "PP", "amdr_dense_reserve": "Pii", "amdr_dense_search": "PPiiPP",
-    "amdr_dense_search_device": "PPiiPPP", "amdr_dense_search_fuse_device": "PPiiPPPPiPPPPPPPP", "amdr_hybrid_small_device": "PPPPPiiiPPPPPPPPPPPP", "amdr_dense_small_create": "PP", "amdr_dense_small_approx_device": "PPiPlPP", "amdr_dense_small_destroy": "P", "amdr_dense_read_rows": "PllP", "amdr_dense_score_rows": "PPiPiP",
+    "amdr_dense_search_device": "PPiiPPP", "amdr_dense_search_fuse_device": "PPiiPPPPiPPPPPPPP", "amdr_hybrid_small_device": "PPPPPiiiPPPPPPPPPPPP", "amdr_dense_small_create": "PP", "amdr_dense_small_approx_device": "PPiPlPP", "amdr_dense_small_destroy": "P", "amdr_dense_two_pass_fallbacks": "PP", "amdr_dense_read_rows": "PllP", "amdr_dense_score_rows": "PPiPiP",
     "amdr_dense_plan_info": "PiiPi", "amdr_dense_workspace_plan": "liiiP", "amdr_dense_hi_counters": "PP", "amdr_dense_profile_begin": "Pi", "amdr_dense_profile_end": "PPP", "amdr_dense_destroy": "P",
     "amdr_bm25_create": "PPPPPlldddiP", "amdr_bm25_ndocs": "PP", "amdr_bm25_reserve": "Piil",
     "amdr_bm25_search": "PPPiiPP", "amdr_bm25_search_device": "PPPiiPPP", "amdr_bm25_scores": "PPPiP",
@@ -247,6 +247,12 @@ class DenseIndex:
     def search_device(self, q_ptr: int, nq: int, k: int, scores_ptr: int, ids_ptr: int, stream: int = 0) -> None:
         _check(load().amdr_dense_search_device(self._h, _vp(q_ptr), C.c_int32(nq), C.c_int32(k), _vp(scores_ptr),
                                                _vp(ids_ptr), _vp(stream)), "amdr_dense_search_device")
+
+    def two_pass_fallbacks(self) -> int:
+        """Queries of the two-pass long-batch searches so far that re-scored their whole row (amdr_dense_two_pass_fallbacks)."""
+        out = C.c_int64(0)
+        _check(load().amdr_dense_two_pass_fallbacks(self._h, C.byref(out)), "amdr_dense_two_pass_fallbacks")
+        return int(out.value)
 
     def search_fuse_device(self, params: "FuseParams", q_ptr: int, nq: int, k: int, bm25, dense_row2uid: int,
                            scores_ptr: int, ids_ptr: int, out_ids: int, out_vals: int, out_mask: int, out_count: int,

@@ -1489,6 +1489,18 @@ int amdr_dense_profile_end(amdr_dense_t* h, double* total_ms, int32_t* launches)
   return AMDR_OK;
 }
 
+int amdr_dense_two_pass_fallbacks(amdr_dense_t* h, int64_t* out) {
+  AMDR_REQUIRE(h && out, "dense_two_pass_fallbacks: null");
+  *out = 0;
+  std::lock_guard<std::mutex> g(h->mu);
+  if (!h->small_fb.p) return AMDR_OK;
+  AMDR_HIP(hipSetDevice(h->device));
+  unsigned int v = 0;
+  AMDR_HIP(hipMemcpy(&v, h->small_fb.p, sizeof(v), hipMemcpyDeviceToHost));  // (synchronises with the device)
+  *out = (int64_t)v;
+  return AMDR_OK;
+}
+
 int amdr_dense_destroy(amdr_dense_t* h) {
   if (!h) return AMDR_OK;
   (void)hipSetDevice(h->device);

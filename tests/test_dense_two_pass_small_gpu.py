@@ -47,7 +47,9 @@ def test_two_pass_equals_the_exact_form_and_the_oracle(n, d, nq, k):
     two = {"AMDR_DENSE_SMALL_HI": "1", "AMDR_DENSE_SMALL_HI_MIN": "96"}
     s2, i2, plan2 = _search(idx, Q, k, two)
     s1, i1, plan1 = _search(idx, Q, k, {"AMDR_DENSE_SMALL_HI": "0"})
+    before = idx.two_pass_fallbacks()
     sf, i_f, _ = _search(idx, Q, k, dict(two, AMDR_DENSE_SMALL_HI_MARGIN="1e9"))  # every query: the exact fallback inside
+    assert idx.two_pass_fallbacks() - before == (nq if n > 32 else 0)  # (<= 32 rows: all of them are candidates anyway)
     assert plan2.startswith("dsh_scores_kernel") and not plan1.startswith("dsh_scores_kernel")
     es, ei = OD.flatip_topk(X, Q, k)
     for s, i, what in ((s2, i2, "two-pass"), (sf, i_f, "fallback"), (s1, i1, "exact")):
