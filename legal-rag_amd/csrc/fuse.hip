@@ -722,7 +722,8 @@ __global__ __launch_bounds__(64) void dense_hi_select_fuse_kernel(amdr_fuse_para
     if (exact_all) need = 0;
   }
   if (__any(exact_all)) {  // wave-uniform: one of the two halves (or both) re-scores its whole row
-    if (lane == 0 && fallbacks) atomicAdd(fallbacks, (unsigned int)__popcll(__ballot(exact_all && sl == 0)));
+    const unsigned long long fbm = __ballot(exact_all && sl == 0);  // (one lane per half)
+    if (lane == 0 && fallbacks) atomicAdd(fallbacks, (unsigned int)__popcll(fbm));
     const C32 keep = out;
     const int keep_need = need, keep_got = got;
     // the exact scores of the half's whole row, in LDS (two rows of 1 024 floats behind the selectors' scratch), then the
