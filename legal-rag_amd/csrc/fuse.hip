@@ -566,7 +566,7 @@ __device__ __forceinline__ int select_row_pair_margin(const float* __restrict__ 
   for (int u = 0; u < V / 4; ++u) {
     const long c0 = 128L * u + 4 * j;
     const tk_v4f z = {0.f, 0.f, 0.f, 0.f};
-    blk[u] = (has_q && c0 < ldS) ? *reinterpret_cast<const tk_v4f*>(row + c0) : z;
+    blk[u] = (has_q && c0 < ldS) ? __builtin_nontemporal_load(reinterpret_cast<const tk_v4f*>(row + c0)) : z;  // read once
   }
   u32 sk[V];
 #pragma unroll
@@ -671,7 +671,8 @@ __global__ __launch_bounds__(64) void dense_hi_select_fuse_kernel(amdr_fuse_para
 #pragma unroll
   for (int u = 0; u < D128; ++u) {
     const tk_v4f z = {0.f, 0.f, 0.f, 0.f};
-    qv[u] = has_q ? *reinterpret_cast<const tk_v4f*>(Q + (size_t)q * d + 128 * u + 4 * sl) : z;
+    qv[u] = has_q ? __builtin_nontemporal_load(reinterpret_cast<const tk_v4f*>(Q + (size_t)q * d + 128 * u + 4 * sl)) : z;  // (the
+    // streamed score rows and queries are read once: non-temporal, so that the chunk rows the candidates re-read stay in L2)
   }
   // the sum of a value over the 32 lanes of each half, in every lane of the half: five DPP row operations leave the halves'
   // sums in lanes 31 and 63 (dense_dot.hpp), two v_readlane hand them out — no LDS round trips (ds_bpermute shuffles made
