@@ -14,6 +14,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Optional
 
+import os
+
 import torch
 
 from .. import _native
@@ -261,15 +263,36 @@ class HybridEngine:
             res.dense_scores, res.dense_ids = d
             res.bm25_scores, res.bm25_ids = b
             return res
-        if self.dense is not None and q_emb is not None:
-            d = self.dense_topk(q_emb, k)
-            nq = q_emb.shape[0]
-        if self.bm25 is not None and q_ptr is not None:
-            b = self.bm25_topk(q_terms, q_ptr, k)
-            nq = q_ptr.shape[0] - 1
-        if self.maxsim is not None and q_tok is not None:
+        with_col = self.maxsim is not None and q_tok is not None
+        overlap = (with_col and os.environ.get("AMDR_ENGINE_OVERLAP", "1") != "0"
+                   and ((self.dense is not None and q_emb is not None) or (self.bm25 is not None and q_ptr is not None)))
+        if overlap:
+            # The dense and BM25 channels of a batch are a few short launches that do not fill the chip; MaxSim's first pass is
+            # ~0.8 ms on the matrix pipe.  They depend on nothing of each other until the fusion: the two short channels go to
+            # a side stream (forked from and joined to the caller's: inside a hipGraph capture the fork / join become edges).
+            main = torch.cuda.current_stream(self.tdev)
+            side = self.__dict__.get("_side_stream")
+            if side is None:
+                side = self.__dict__["_side_stream"] = torch.cuda.Stream(device=self.tdev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                if self.dense is not None and q_emb is not None:
+                    d = self.dense_topk(q_emb, k)
+                if self.bm25 is not None and q_ptr is not None:
+                    b = self.bm25_topk(q_terms, q_ptr, k)
             c = self.colbert_topk(q_tok, k)
+            main.wait_stream(side)
             nq = q_tok.shape[0]
+        else:
+            if self.dense is not None and q_emb is not None:
+                d = self.dense_topk(q_emb, k)
+                nq = q_emb.shape[0]
+            if self.bm25 is not None and q_ptr is not None:
+                b = self.bm25_topk(q_terms, q_ptr, k)
+                nq = q_ptr.shape[0] - 1
+            if with_col:
+                c = self.colbert_topk(q_tok, k)
+                nq = q_tok.shape[0]
         if self.shard_offset is not None:
             from . import sharding
             chans = [x for x in (d, b, c) if x is not None]
