@@ -777,7 +777,7 @@ __global__ __launch_bounds__(64) void dense_hi_select_fuse_kernel(amdr_fuse_para
   // two candidates per step: both rows requested before either is summed.  (Tried: the NEXT step's rows requested before
   // this step's are summed, two register sets in ping-pong — 146 VGPRs, three waves per SIMD instead of four: 119.5 against
   // 119.1 us; the kernel issues 2 289 vector instructions per wave = 56 % of its time and waits on memory for half of it.
-  // The other direction, amdgpu_waves_per_eu(5) / (6): 96 / 80 VGPRs with 4 / 172 spilled — the step 0.258 -> 0.279 / 0.291 ms.)
+  // The other direction, amdgpu_waves_per_eu(5) / (6): registers capped at 96 / 80, the rest spilled (4 / 172 at d = 384, more at 768) — the d = 768 step 0.258 -> 0.279 / 0.291 ms.)
   for (int c = 0; c < steps; c += 2) {  // (steps: wave-uniform)
     // candidates c, c + 1 of each half: their lanes are wave-uniform (v_readlane), the half picks its own
     const int c1 = c + 1 < 32 ? c + 1 : 31;

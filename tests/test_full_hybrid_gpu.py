@@ -46,6 +46,60 @@ def test_batched_full_hybrid_with_rerank_equals_oracle(lang, n_chunks):
     R.close()
 
 
+def test_side_stream_channels_equal_the_one_stream_batch_eager_and_captured(monkeypatch):
+    """engine.search_batch with ColBERT: the dense and BM25 channels on a side stream beside MaxSim (default) against all
+    three on the caller's stream (AMDR_ENGINE_OVERLAP=0) — same bits; and the forked form captured into a hipGraph and
+    replayed on fresh inputs."""
+    import torch
+
+    import bench
+    from legal_rag_amd import _native
+    W = bench.build_corpus("en", colbert=True)
+    R = bench.Resident(torch, W, 0, rep=1, colbert=True)
+    K = 10
+    R.reserve(K)
+    params = _native.make_fuse_params(w_dense=0.6, w_bm25=0.4, w_colbert=0.35, min_final_score=0.2)
+
+    def snap():
+        res = R.search_batch(params, K)
+        torch.cuda.synchronize()
+        return res, (res.ids.cpu().numpy().copy(), res.vals.cpu().numpy().copy(), res.count.cpu().numpy().copy())
+
+    monkeypatch.setenv("AMDR_ENGINE_OVERLAP", "0")
+    _, one = snap()
+    monkeypatch.setenv("AMDR_ENGINE_OVERLAP", "1")
+    for _ in range(3):
+        _, two = snap()
+        assert (one[2] == two[2]).all()
+        for q in range(one[0].shape[0]):
+            c = int(one[2][q])
+            assert (one[0][q, :c] == two[0][q, :c]).all() and (one[1][q, :c].view("uint64") == two[1][q, :c].view("uint64")).all(), q  # (vals: f64 [.., 9])
+    assert R.eng.__dict__.get("_side_stream") is not None
+    # captured: the fork / join become edges of the graph; replay after the inputs changed and were restored
+    cap = torch.cuda.Stream()
+    cap.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cap):
+        R.search_batch(params, K)
+    torch.cuda.current_stream().wait_stream(cap)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=cap):
+        res = R.search_batch(params, K)
+    keep = R.q_emb.clone()
+    R.q_emb.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert not (res.ids.cpu().numpy()[:, :K] == one[0][:, :K]).all()  # (the dense channel saw zero queries)
+    R.q_emb.copy_(keep)
+    g.replay()
+    torch.cuda.synchronize()
+    ids, cnt = res.ids.cpu().numpy(), res.count.cpu().numpy()
+    assert (cnt == one[2]).all()
+    for q in range(ids.shape[0]):
+        assert (ids[q, :int(cnt[q])] == one[0][q, :int(cnt[q])]).all(), q
+    R.close()
+
+
 def test_language_routed_api_default_hybrid_on_full_fixtures(tmp_path):
     """ByLangRetriever -> HybridRetriever(lang).search with ColBERT and rerank ON over the full
     fixtures, indexes built by the product builders; a sample of queries per language against the
