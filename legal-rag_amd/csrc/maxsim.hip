@@ -1564,10 +1564,28 @@ int ms_run(amdr_maxsim* h, const float* Q_dev, int nq, int q_len, int k, float* 
     AMDR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     if (by_doc) {
       hipLaunchKernelGGL(maxsim_items_kernel, dim3(1), dim3(256), 0, st, dcnt, (long)h->n_docs, h->doc_ptr, ioff, items);
-      AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_rescore_ring_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   4 * 16384));
-      hipLaunchKernelGGL((maxsim_rescore_ring_kernel<4>), dim3(2 * cus), dim3(kMsQ * 64), 4 * 16384, st, h->img,
-                         (long)h->n_docs, img_q, unscale_q, q_len, unscale_d, items, ioff, dlist, nq, exact);
+      const char* e_rr = getenv("AMDR_MAXSIM_RESCORE_RING");
+      const char* e_rb = getenv("AMDR_MAXSIM_RESCORE_BLOCKS");
+      // Ring depth and blocks per CU of the re-scoring pass (same process, interleaved, 1 168 UCC-en queries, whole channel):
+      // 4 stages x 2 blocks per CU (64 KB of LDS each: 4 waves per SIMD) 0.8916 ms; 3 x 3: 0.8903; 2 x 4 (8 waves per SIMD):
+      // 0.8837; 2 stages with 6 / 8 blocks per CU in the grid (the items then outnumber the blocks by little: the hardware
+      // deals them) 0.8815 / 0.8793.  What the deeper ring bought inside a block, twice the resident waves buy across
+      // blocks: the per-item latencies (descriptor -> query list -> query fragments -> first tile) overlap another
+      // block's products.  Civil-Code-zh: 1.1017 -> 1.0947.
+      const int rr = e_rr ? atoi(e_rr) : 2;
+      const int rb = e_rb ? atoi(e_rb) : (rr == 3 ? 3 : rr == 2 ? 8 : 2);
+#define AMDR_MS_RESCORE(NB)                                                                                              \
+  do {                                                                                                                   \
+    AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_rescore_ring_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                 NB * 16384));                                                                           \
+    hipLaunchKernelGGL((maxsim_rescore_ring_kernel<NB>), dim3((rb >= 1 && rb <= 8 ? rb : 2) * cus), dim3(kMsQ * 64),     \
+                       NB * 16384, st, h->img, (long)h->n_docs, img_q, unscale_q, q_len, unscale_d, items, ioff, dlist,  \
+                       nq, exact);                                                                                       \
+  } while (0)
+      if (rr == 3) AMDR_MS_RESCORE(3);
+      else if (rr == 2) AMDR_MS_RESCORE(2);
+      else AMDR_MS_RESCORE(4);
+#undef AMDR_MS_RESCORE
     } else {
       AMDR_HIP(hipFuncSetAttribute((const void*)maxsim_rescore_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds));
       hipLaunchKernelGGL(maxsim_offsets_kernel, dim3(1), dim3(256), 0, st, cnt, nq, off);
@@ -1731,7 +1749,7 @@ int amdr_maxsim_plan_info(const amdr_maxsim_t* h, int32_t nq, char* buf, int32_t
              "(hi + lo/2048, 3 MFMAs per block, candidates only) + %s; full score rows: maxsim_scores_ring_kernel",
              (getenv("AMDR_MAXSIM_RESCORE") && getenv("AMDR_MAXSIM_RESCORE")[0] == '0')
                  ? "maxsim_rescore_kernel (one wave per candidate pair)"
-                 : "maxsim_rescore_ring_kernel (pairs grouped by document: a block = one document x 8 of its queries)",
+                 : "maxsim_rescore_ring_kernel<2> (pairs grouped by document: a block = one document x 8 of its queries; 8 blocks per CU)",
              (getenv("AMDR_MAXSIM_FINAL") && getenv("AMDR_MAXSIM_FINAL")[0] == '0')
                  ? "rowscores_topk_kernel"
                  : "maxsim_final_topk_kernel (the candidates only)");
