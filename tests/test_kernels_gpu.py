@@ -680,9 +680,19 @@ def test_maxsim_two_pass_topk_equals_one_pass(nat, monkeypatch):
             idx = nat.MaxSimIndex(D, doc_ptr)
             out[flag] = idx.search(Q, k)
             idx.close()
-        for name in ("AMDR_MAXSIM_RESCORE", "AMDR_MAXSIM_PRESPLIT", "AMDR_MAXSIM_FINAL"):
+        # the re-scoring pass's ring depth / blocks per CU (default 2 stages, grid of 8 blocks per CU): the persistent
+        # form of the start of the round (4 stages, 2 blocks per CU) and one block per CU (every block walks many items)
+        for flag, ring, blocks in (("1g4", "4", "2"), ("1g3", "3", "1")):
+            monkeypatch.setenv("AMDR_MAXSIM_TWOPASS", "1")
+            monkeypatch.setenv("AMDR_MAXSIM_RESCORE_RING", ring)
+            monkeypatch.setenv("AMDR_MAXSIM_RESCORE_BLOCKS", blocks)
+            idx = nat.MaxSimIndex(D, doc_ptr)
+            out[flag] = idx.search(Q, k)
+            idx.close()
+        for name in ("AMDR_MAXSIM_RESCORE", "AMDR_MAXSIM_PRESPLIT", "AMDR_MAXSIM_FINAL", "AMDR_MAXSIM_RESCORE_RING",
+                     "AMDR_MAXSIM_RESCORE_BLOCKS"):
             monkeypatch.delenv(name)
-        for other in ("0", "1r3", "1w"):
+        for other in ("0", "1r3", "1w", "1g4", "1g3"):
             assert np.array_equal(out["1"][1], out[other][1]), (k, other)
             assert np.array_equal(out["1"][0], out[other][0]), (k, other)
         return out["1"]
