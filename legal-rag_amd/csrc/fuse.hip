@@ -582,19 +582,25 @@ __device__ __forceinline__ int select_row_pair_margin(const float* __restrict__ 
   for (int v = 0; v < V; ++v) lb.c = sk[v] > lb.c ? sk[v] : lb.c;
   const K32 sorted_best = wave_sortN_desc<K32, 32>(lb, lane);
   const int kk = (k - 1 < 31 ? k - 1 : 31);
-  const u32 T = (u32)__shfl((int)sorted_best.c, (lane & 32) + kk);  // k-th lane best of this half: <= the k-th best score
+  // (cross-lane reads at wave-uniform positions are two v_readlane and a select; the prefix sum below is five DPP row
+  // operations — __shfl / __shfl_up are LDS round trips, eight of them per call of this selector before)
+  auto half_lane = [&](int x, int pos) -> int {  // lane `pos` of this lane's half
+    const int a = __builtin_amdgcn_readlane(x, pos), b = __builtin_amdgcn_readlane(x, 32 + pos);
+    return (lane & 32) ? b : a;
+  };
+  const u32 T = (u32)half_lane((int)sorted_best.c, kk);  // k-th lane best of this half: <= the k-th best score
   // the rows at or above a key threshold -> this half's 32 scratch slots, sorted into the lanes; -1: more than 32
   auto gather = [&](u32 Te, C32& c) -> int {
     int mine = 0;
 #pragma unroll
     for (int v = 0; v < V; ++v) mine += (sk[v] >= Te) ? 1 : 0;
-    int incl = mine;
-#pragma unroll
-    for (int sft = 1; sft < 32; sft <<= 1) {
-      const int o = __shfl_up(incl, sft, 32);
-      incl += (j >= sft) ? o : 0;
-    }
-    const int cnt = __shfl(incl, (lane & 32) + 31);
+    int incl = mine;  // inclusive prefix sum over the 32 lanes of the half (rows of 16, then row 0 -> 1, 2 -> 3)
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);  // row_shr:1
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);  // row_shr:2
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);  // row_shr:4
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);  // row_shr:8
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1, 3
+    const int cnt = half_lane(incl, 31);
     if (cnt > 32) return -1;
     int at = (lane & 32) + incl - mine;
 #pragma unroll
@@ -623,7 +629,7 @@ __device__ __forceinline__ int select_row_pair_margin(const float* __restrict__ 
   // when the margin reaches below the lane-maximum threshold the row is swept again with the cut itself.
   u32 cut = 1u;
   if (cnt > kk) {
-    const float tk_f = __shfl(c.score(), (lane & 32) + kk);
+    const float tk_f = __int_as_float(half_lane(__float_as_int(c.score()), kk));
     cut = ord32(tk_f - margin);
     cut = cut > 1u ? cut : 1u;
   }
